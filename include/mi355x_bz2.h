@@ -1,0 +1,206 @@
+/*
+ * mi355x_bz2.h -- C ABI of the MI355X-native parallel bzip2 block decoder.
+ *
+ * This is the drop-in boundary for ONE path of WeGoToMars/indexed_bzip2: decoding independent bzip2 blocks behind
+ * ParallelBZ2Reader / ibzip2.open().  Everything is `extern "C"`, plain pointers and sizes.  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Layers exported here:
+ *   1. Block codec on the GPU (the operator seam):      mi355x_bz2_create / _set_input_* / _decode_batch / ...
+ *        replaces  BZ2BlockFetcher::decodeBlock          src/indexed_bzip2/BZ2BlockFetcher.hpp:85-138
+ *                  (virtual BlockFetcher::decodeBlock    src/core/BlockFetcher.hpp:580-582)
+ *        and everything it calls: bzip2::Block           src/indexed_bzip2/bzip2.hpp:145-461, 479-910
+ *   2. Host magic-bit scan:                              mi355x_bz2_find_magic
+ *        replaces  BitStringFinder<48>::find             src/core/BitStringFinder.hpp:158-285
+ *                  ParallelBitStringFinder<48>::find     src/core/ParallelBitStringFinder.hpp:159-265
+ *   3. Reader (scheduler + block map + user API):        mi355x_bz2_reader_*
+ *        replaces  indexed_bzip2::ParallelBZ2Reader      src/indexed_bzip2/ParallelBZ2Reader.hpp:39-498
+ *                  (BZ2ReaderInterface                   src/indexed_bzip2/BZ2ReaderInterface.hpp:15-103)
+ *        as bound by the Cython module                   python/indexed_bzip2/indexed_bzip2.pyx:26-67
+ *
+ * No exceptions cross this ABI: every reference throw site on the path has a status code below; the host-side
+ * scheduler turns a non-OK status back into the reference's behaviour (prefetch failures are silent, on-demand
+ * failures surface from read(); src/core/BlockFetcher.hpp:305, 424-432).
+ */
+#ifndef MI355X_BZ2_H
+#define MI355X_BZ2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_BZ2_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------------ status codes */
+typedef enum mi355x_bz2_status {
+    MI355X_BZ2_OK = 0,
+    MI355X_BZ2_ERR_EOF = 1,               /* BitReader::EndOfFileReached            src/core/BitReader.hpp:82-84 */
+    MI355X_BZ2_ERR_BAD_MAGIC = 2,         /* "invalid compressed magic"             bzip2.hpp:502-507 */
+    MI355X_BZ2_ERR_RANDOMIZED = 3,        /* "isRandomized bit is not supported"    bzip2.hpp:509-512 */
+    MI355X_BZ2_ERR_ORIGPTR_RANGE = 4,     /* "origPtr ... larger than buffer size"  bzip2.hpp:514-519 */
+    MI355X_BZ2_ERR_GROUP_COUNT = 5,       /* "Invalid Huffman coding group count"   bzip2.hpp:579-583 */
+    MI355X_BZ2_ERR_SELECTOR_COUNT = 6,    /* "number of selectors ... invalid"      bzip2.hpp:593-597 */
+    MI355X_BZ2_ERR_SELECTOR_UNARY = 7,    /* "Could not find zero termination"      bzip2.hpp:625-629 */
+    MI355X_BZ2_ERR_CODE_LENGTH = 8,       /* "start_huffman_length ..."             bzip2.hpp:657-662 */
+    MI355X_BZ2_ERR_HUFFMAN_LENGTHS = 9,   /* Error::INVALID_CODE_LENGTHS            bzip2.hpp:680-683 */
+    MI355X_BZ2_ERR_SELECTOR_OVERRUN = 10, /* "selector ... out of maximum range"    bzip2.hpp:714-718 */
+    MI355X_BZ2_ERR_INVALID_CODE = 11,     /* std::bad_optional_access               bzip2.hpp:723 */
+    MI355X_BZ2_ERR_RUN_OVERFLOW = 12,     /* "dbufCount + hh ... > dbufSize"        bzip2.hpp:751-756 */
+    MI355X_BZ2_ERR_DATA_OVERFLOW = 13,    /* "dbufCount ... > dbufSize"             bzip2.hpp:776-780 */
+    MI355X_BZ2_ERR_ORIGPTR_DATA = 14,     /* "origPtr error"                        bzip2.hpp:794-798 */
+    MI355X_BZ2_ERR_CRC = 15,              /* "Calculated CRC ... mismatches"        bzip2.hpp:900-907 */
+    MI355X_BZ2_ERR_STREAM_HEADER = 16,    /* readBzip2Header                        bzip2.hpp:114-142 */
+
+    /* errors of this implementation, no reference counterpart */
+    MI355X_BZ2_ERR_OUTPUT_CAPACITY = 100,
+    MI355X_BZ2_ERR_DEVICE = 101,          /* HIP runtime error (see mi355x_bz2_last_error) */
+    MI355X_BZ2_ERR_NO_DEVICE = 102,       /* no gfx950 device / HIP extension unusable: the product path has NO CPU fallback */
+    MI355X_BZ2_ERR_INVALID_ARGUMENT = 103,
+    MI355X_BZ2_ERR_IO = 104,
+    MI355X_BZ2_ERR_CLOSED = 105,
+    MI355X_BZ2_ERR_LOGIC = 106
+} mi355x_bz2_status;
+
+const char* mi355x_bz2_status_string( int status );
+int mi355x_bz2_abi_version( void );
+
+/* ------------------------------------------------------------------------------------------------ 1. block codec */
+
+typedef struct mi355x_bz2_ctx mi355x_bz2_ctx;
+
+typedef struct mi355x_bz2_config {
+    int32_t  device;              /* HIP device ordinal; -1 = current device */
+    uint32_t max_batch_blocks;    /* initial scratch capacity in blocks (grows on demand); 0 = default 64 */
+    uint32_t flags;               /* MI355X_BZ2_FLAG_* */
+    uint32_t reserved;
+} mi355x_bz2_config;
+
+#define MI355X_BZ2_FLAG_KEEP_STAGES 1u   /* keep per-stage buffers addressable for mi355x_bz2_debug_copy_stage */
+
+/* Mirrors indexed_bzip2::BlockData / BlockHeaderData (src/indexed_bzip2/BZ2BlockFetcher.hpp:18-34); `data` is the
+ * byte range [data_offset, data_offset + decoded_size) of the batch output buffer. */
+typedef struct mi355x_bz2_block_result {
+    uint64_t encoded_offset_bits;   /* BlockHeaderData::encodedOffsetInBits */
+    uint64_t encoded_size_bits;     /* BlockHeaderData::encodedSizeInBits */
+    uint64_t decoded_size;          /* BlockData::data.size()  (D) */
+    uint64_t data_offset;           /* offset of this block's bytes in the batch output buffer */
+    uint32_t header_crc;            /* BlockHeaderData::expectedCRC (stream CRC for an EOS block) */
+    uint32_t computed_crc;          /* BlockData::calculatedCRC */
+    uint32_t bwt_length;            /* N: symbols in dbuf after readBlockData (roofline accounting) */
+    uint32_t orig_ptr;
+    uint32_t n_symbols;             /* Huffman symbols decoded incl. end-of-block */
+    int32_t  is_eos;                /* BlockHeaderData::isEndOfStreamBlock */
+    int32_t  is_eof;                /* BlockHeaderData::isEndOfFile */
+    int32_t  status;                /* mi355x_bz2_status */
+} mi355x_bz2_block_result;
+
+/* Device time of the last decode_batch per pipeline stage, measured with HIP events on the ctx stream. */
+typedef struct mi355x_bz2_timings {
+    float ms_total;          /* first kernel start .. last kernel end */
+    float ms_huffman;        /* header parse + Huffman + MTF + RLE2  -> L column */
+    float ms_bwt_build;      /* histogram + rank -> packed LF table */
+    float ms_walk;           /* multi-segment permutation walk (both passes) + segment linking */
+    float ms_rle_crc;        /* RLE1 sizing, expansion and CRC */
+    float ms_reserved[3];
+} mi355x_bz2_timings;
+
+/* Create / destroy a decoder context bound to one GPU and one HIP stream.
+ * Fails with MI355X_BZ2_ERR_NO_DEVICE when no usable gfx950 device exists: there is no CPU fallback. */
+int  mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** ctx );
+void mi355x_bz2_destroy( mi355x_bz2_ctx* ctx );
+const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
+
+/* Make the compressed file (or any byte range of it; bit offsets below are relative to `bytes[0]`) resident in HBM.
+ * _host copies H2D into ctx-owned memory.  _device borrows a device pointer (must stay valid; size need not be padded).
+ * Replaces the BitReader/SharedFileReader clone + pread of BZ2BlockFetcher.hpp:89-90. */
+int mi355x_bz2_set_input_host( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
+int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, uint64_t size );
+
+/* Decode n_blocks independent blocks whose magic starts at block_bit_offsets[i] (from the finder or the index).
+ * = n calls of BZ2BlockFetcher::decodeBlock (BZ2BlockFetcher.hpp:85-138).  An offset pointing at an EOS magic
+ * returns is_eos=1 and no data (ibid. :101-104).  results[i].status reports per-block failures; the function's
+ * own return value is non-OK only for argument/device failures.  Decoded bytes stay in HBM (ctx-owned, valid
+ * until the next decode_batch/destroy); *total_decoded = sum of decoded_size. */
+int mi355x_bz2_decode_batch( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offsets, uint32_t n_blocks,
+                             mi355x_bz2_block_result* results, uint64_t* total_decoded );
+
+/* Device pointer of the last batch's ragged output buffer (block i at data_offset). */
+const void* mi355x_bz2_output_device( const mi355x_bz2_ctx* ctx );
+/* Copy [offset, offset+size) of the last batch's output to host memory (D2H). */
+int mi355x_bz2_copy_output( mi355x_bz2_ctx* ctx, uint64_t offset, uint64_t size, void* host_dst );
+int mi355x_bz2_last_timings( const mi355x_bz2_ctx* ctx, mi355x_bz2_timings* timings );
+/* The hipStream_t the context launches on (as void*), so callers can order their own work after it. */
+void* mi355x_bz2_stream( const mi355x_bz2_ctx* ctx );
+
+/* Debug/parity hook (needs MI355X_BZ2_FLAG_KEEP_STAGES): copy an intermediate stage of block `index` of the last
+ * batch to host. stage 0 = L column (N bytes, bzip2.hpp:789 dbuf low bytes), 1 = packed LF table (4N bytes),
+ * 2 = inverse-BWT output before RLE1 (N bytes). */
+int mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* ctx, uint32_t index, int stage, void* host_dst, uint64_t capacity );
+
+/* ------------------------------------------------------------------------------------------------ 2. magic scan */
+
+#define MI355X_BZ2_MAGIC_BLOCK 0x314159265359ULL   /* bzip2.hpp:103 */
+#define MI355X_BZ2_MAGIC_EOS   0x177245385090ULL   /* bzip2.hpp:104 */
+
+/* All bit offsets (ascending) at which the 48-bit pattern occurs in bytes[0,size).  Returns the number found; at most
+ * `capacity` are written.  `threads` = 0 picks the host's core count.
+ * Replaces ParallelBitStringFinder<48>::find (src/core/ParallelBitStringFinder.hpp:159-265). */
+uint64_t mi355x_bz2_find_magic( const uint8_t* bytes, uint64_t size, uint64_t magic48,
+                                uint64_t* bit_offsets, uint64_t capacity, uint32_t threads );
+
+/* bzip2::readBzip2Header (bzip2.hpp:114-142) at a byte-aligned bit offset: returns level 1..9, or 0 if invalid. */
+int mi355x_bz2_read_stream_header( const uint8_t* bytes, uint64_t size, uint64_t bit_offset );
+
+/* ------------------------------------------------------------------------------------------------ 3. reader */
+
+typedef struct mi355x_bz2_reader mi355x_bz2_reader;
+
+/* ParallelBZ2Reader( filePath | fd | memory, parallelization )    ParallelBZ2Reader.hpp:50-89
+ * parallelization = number of blocks kept in flight per GPU batch (0 = default). */
+int mi355x_bz2_reader_open_path( const char* path, uint32_t parallelization, int32_t device, mi355x_bz2_reader** r );
+int mi355x_bz2_reader_open_fd( int fd, uint32_t parallelization, int32_t device, mi355x_bz2_reader** r );
+int mi355x_bz2_reader_open_memory( const uint8_t* bytes, uint64_t size, uint32_t parallelization, int32_t device,
+                                   mi355x_bz2_reader** r );
+void mi355x_bz2_reader_close( mi355x_bz2_reader* r );                        /* close()        :104-111 */
+const char* mi355x_bz2_reader_last_error( const mi355x_bz2_reader* r );
+
+/* read( fd, buffer, n ): writes to `fd` if fd >= 0, else copies to `buffer` if non-NULL, else discards
+ * (BZ2ReaderInterface.hpp:35-57 + ParallelBZ2Reader.hpp:167-269).  *n_read = bytes produced. */
+int mi355x_bz2_reader_read( mi355x_bz2_reader* r, int fd, void* buffer, uint64_t n_bytes, uint64_t* n_read );
+/* seek( offset, whence ) with SEEK_SET/SEEK_CUR/SEEK_END          ParallelBZ2Reader.hpp:271-325 */
+int mi355x_bz2_reader_seek( mi355x_bz2_reader* r, int64_t offset, int whence, uint64_t* new_position );
+uint64_t mi355x_bz2_reader_tell( const mi355x_bz2_reader* r );                /* tell()         :129-142 */
+int      mi355x_bz2_reader_eof( const mi355x_bz2_reader* r );                 /* eof()          :119-123 */
+int      mi355x_bz2_reader_closed( const mi355x_bz2_reader* r );              /* closed()       :113-117 */
+/* size(): returns 1 and *size if the block map is finalized, else 0             :144-151 */
+int      mi355x_bz2_reader_size( const mi355x_bz2_reader* r, uint64_t* size );
+uint64_t mi355x_bz2_reader_tell_compressed( const mi355x_bz2_reader* r );     /* tellCompressed :385-393 */
+int      mi355x_bz2_reader_block_offsets_complete( const mi355x_bz2_reader* r ); /*             :329-333 */
+
+/* blockOffsets() (forces a full decode) / availableBlockOffsets(): two-call protocol -- pass capacity 0 to get the
+ * count in *n, then call again with arrays of that size.                         :339-363 */
+int mi355x_bz2_reader_block_offsets( mi355x_bz2_reader* r, uint64_t* bits, uint64_t* bytes, uint64_t capacity,
+                                     uint64_t* n );
+int mi355x_bz2_reader_available_block_offsets( const mi355x_bz2_reader* r, uint64_t* bits, uint64_t* bytes,
+                                               uint64_t capacity, uint64_t* n );
+/* setBlockOffsets( map )                                                       :365-378 */
+int mi355x_bz2_reader_set_block_offsets( mi355x_bz2_reader* r, const uint64_t* bits, const uint64_t* bytes,
+                                         uint64_t n );
+/* joinThreads()                                                                :404-409 */
+int mi355x_bz2_reader_join_threads( mi355x_bz2_reader* r );
+
+/* BlockFetcher::Statistics subset (src/core/BlockFetcher.hpp:52-173) */
+typedef struct mi355x_bz2_reader_stats {
+    uint64_t gets, cache_hits, prefetch_hits, on_demand_fetches, prefetches_submitted, batches, blocks_decoded;
+    uint64_t failed_prefetches;
+    double   decode_seconds, wait_seconds;
+} mi355x_bz2_reader_stats;
+int mi355x_bz2_reader_statistics( const mi355x_bz2_reader* r, mi355x_bz2_reader_stats* stats );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_BZ2_H */

@@ -1,0 +1,8 @@
+"""indexed_bzip2_amd -- MI355X-native parallel bzip2 block decoder behind the indexed_bzip2 API.
+
+Host-side mirror of python/indexed_bzip2/indexed_bzip2.pyx (open, IndexedBzip2File, ...) over the C ABI of
+include/mi355x_bz2.h.  All decoding happens in hand-written HIP kernels on gfx950; there is no CPU fallback.
+"""
+__version__ = "0.1.0"
+
+from ._native import Bz2Error, Decoder, find_magic, lib, status_string  # noqa: F401

@@ -1,0 +1,211 @@
+"""ctypes binding of the C ABI declared in include/mi355x_bz2.h (libmi355x_bz2.so, built by build.py).
+
+The product path has no CPU fallback: if the HIP library is missing or no MI355X is present, the functions here
+raise -- nothing in this package imports or calls oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355x_bz2.so")
+
+MAGIC_BLOCK = 0x314159265359
+MAGIC_EOS = 0x177245385090
+
+OK = 0
+ERR_CRC = 15
+ERR_NO_DEVICE = 102
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("max_batch_blocks", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class BlockResult(ctypes.Structure):
+    _fields_ = [
+        ("encoded_offset_bits", ctypes.c_uint64),
+        ("encoded_size_bits", ctypes.c_uint64),
+        ("decoded_size", ctypes.c_uint64),
+        ("data_offset", ctypes.c_uint64),
+        ("header_crc", ctypes.c_uint32),
+        ("computed_crc", ctypes.c_uint32),
+        ("bwt_length", ctypes.c_uint32),
+        ("orig_ptr", ctypes.c_uint32),
+        ("n_symbols", ctypes.c_uint32),
+        ("is_eos", ctypes.c_int32),
+        ("is_eof", ctypes.c_int32),
+        ("status", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("ms_total", ctypes.c_float), ("ms_huffman", ctypes.c_float), ("ms_bwt_build", ctypes.c_float),
+                ("ms_walk", ctypes.c_float), ("ms_rle_crc", ctypes.c_float), ("ms_reserved", ctypes.c_float * 3)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in ("ms_total", "ms_huffman", "ms_bwt_build", "ms_walk", "ms_rle_crc")}
+
+
+class ReaderStats(ctypes.Structure):
+    _fields_ = [("gets", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64), ("prefetch_hits", ctypes.c_uint64),
+                ("on_demand_fetches", ctypes.c_uint64), ("prefetches_submitted", ctypes.c_uint64),
+                ("batches", ctypes.c_uint64), ("blocks_decoded", ctypes.c_uint64),
+                ("failed_prefetches", ctypes.c_uint64),
+                ("decode_seconds", ctypes.c_double), ("wait_seconds", ctypes.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/mi355x_bz2.h declares: (name, restype, argtypes)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+SYMBOLS = [
+    ("mi355x_bz2_status_string", ctypes.c_char_p, [ctypes.c_int]),
+    ("mi355x_bz2_abi_version", ctypes.c_int, []),
+    ("mi355x_bz2_create", ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
+    ("mi355x_bz2_destroy", None, [_vp]),
+    ("mi355x_bz2_last_error", ctypes.c_char_p, [_vp]),
+    ("mi355x_bz2_set_input_host", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64]),
+    ("mi355x_bz2_set_input_device", ctypes.c_int, [_vp, _vp, ctypes.c_uint64]),
+    ("mi355x_bz2_decode_batch", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.POINTER(BlockResult), _u64p]),
+    ("mi355x_bz2_output_device", _vp, [_vp]),
+    ("mi355x_bz2_copy_output", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    ("mi355x_bz2_last_timings", ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
+    ("mi355x_bz2_stream", _vp, [_vp]),
+    ("mi355x_bz2_debug_copy_stage", ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_int, _vp, ctypes.c_uint64]),
+    ("mi355x_bz2_find_magic", ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _u64p,
+                                                 ctypes.c_uint64, ctypes.c_uint32]),
+    ("mi355x_bz2_read_stream_header", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
+    ("mi355x_bz2_reader_open_path", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    ("mi355x_bz2_reader_open_fd", ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    ("mi355x_bz2_reader_open_memory", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32,
+                                                      ctypes.POINTER(_vp)]),
+    ("mi355x_bz2_reader_close", None, [_vp]),
+    ("mi355x_bz2_reader_last_error", ctypes.c_char_p, [_vp]),
+    ("mi355x_bz2_reader_read", ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_uint64, _u64p]),
+    ("mi355x_bz2_reader_seek", ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _u64p]),
+    ("mi355x_bz2_reader_tell", ctypes.c_uint64, [_vp]),
+    ("mi355x_bz2_reader_eof", ctypes.c_int, [_vp]),
+    ("mi355x_bz2_reader_closed", ctypes.c_int, [_vp]),
+    ("mi355x_bz2_reader_size", ctypes.c_int, [_vp, _u64p]),
+    ("mi355x_bz2_reader_tell_compressed", ctypes.c_uint64, [_vp]),
+    ("mi355x_bz2_reader_block_offsets_complete", ctypes.c_int, [_vp]),
+    ("mi355x_bz2_reader_block_offsets", ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_uint64, _u64p]),
+    ("mi355x_bz2_reader_available_block_offsets", ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_uint64, _u64p]),
+    ("mi355x_bz2_reader_set_block_offsets", ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_uint64]),
+    ("mi355x_bz2_reader_join_threads", ctypes.c_int, [_vp]),
+    ("mi355x_bz2_reader_statistics", ctypes.c_int, [_vp, ctypes.POINTER(ReaderStats)]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libmi355x_bz2.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -m indexed_bzip2_amd.build). "
+                "indexed_bzip2_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def status_string(status: int) -> str:
+    return lib().mi355x_bz2_status_string(status).decode()
+
+
+class Bz2Error(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = status_string(status)
+        if detail:
+            msg += f" ({detail})"
+        super().__init__(msg)
+
+
+def find_magic(data: bytes, magic: int = MAGIC_BLOCK, threads: int = 0):
+    L = lib()
+    n = L.mi355x_bz2_find_magic(data, len(data), magic, None, 0, threads)
+    arr = (ctypes.c_uint64 * max(1, n))()
+    L.mi355x_bz2_find_magic(data, len(data), magic, arr, n, threads)
+    return list(arr[:n])
+
+
+class Decoder:
+    """One decoder context = one GPU + one HIP stream (mi355x_bz2_ctx)."""
+
+    KEEP_STAGES = 1
+
+    def __init__(self, device: int = -1, max_batch_blocks: int = 0, flags: int = 0):
+        self._h = _vp()
+        cfg = Config(device, max_batch_blocks, flags, 0)
+        rc = lib().mi355x_bz2_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != OK:
+            raise Bz2Error(rc)
+        self._input_ref = None
+        self.last_results = []
+
+    def close(self):
+        if self._h:
+            lib().mi355x_bz2_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise Bz2Error(rc, lib().mi355x_bz2_last_error(self._h).decode())
+
+    def set_input(self, data: bytes):
+        self._check(lib().mi355x_bz2_set_input_host(self._h, data, len(data)))
+
+    def set_input_device(self, ptr: int, size: int, keepalive=None):
+        self._input_ref = keepalive
+        self._check(lib().mi355x_bz2_set_input_device(self._h, ptr, size))
+
+    def decode_batch(self, offsets):
+        n = len(offsets)
+        offs = (ctypes.c_uint64 * max(1, n))(*offsets)
+        res = (BlockResult * max(1, n))()
+        total = ctypes.c_uint64()
+        self._check(lib().mi355x_bz2_decode_batch(self._h, offs, n, res, ctypes.byref(total)))
+        self.last_results = [res[i].as_dict() for i in range(n)]
+        return self.last_results, total.value
+
+    def output_device_ptr(self) -> int:
+        return lib().mi355x_bz2_output_device(self._h) or 0
+
+    def stream_ptr(self) -> int:
+        return lib().mi355x_bz2_stream(self._h) or 0
+
+    def copy_output(self, offset: int, size: int) -> bytes:
+        buf = ctypes.create_string_buffer(max(1, size))
+        self._check(lib().mi355x_bz2_copy_output(self._h, offset, size, buf))
+        return buf.raw[:size]
+
+    def timings(self) -> dict:
+        t = Timings()
+        self._check(lib().mi355x_bz2_last_timings(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
+    def debug_stage(self, index: int, stage: int) -> bytes:
+        n = self.last_results[index]["bwt_length"] * (4 if stage == 1 else 1)
+        buf = ctypes.create_string_buffer(max(1, n))
+        self._check(lib().mi355x_bz2_debug_copy_stage(self._h, index, stage, buf, n))
+        return buf.raw[:n]

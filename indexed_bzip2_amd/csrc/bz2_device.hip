@@ -1,0 +1,452 @@
+/**
+ * bz2_device.hip -- decoder context + batch launcher behind the C ABI of include/mi355x_bz2.h (section 1).
+ *
+ * Replaces BZ2BlockFetcher::decodeBlock (src/indexed_bzip2/BZ2BlockFetcher.hpp:85-138): instead of one block per
+ * host thread, a whole batch of independent blocks is pushed through the kernels of bz2_kernels.hip.h on one HIP
+ * stream.  Per-block scratch lives in HBM and is sized for the largest block the format allows (900 000 symbols):
+ *   L column 0.9 MB, packed LF table 4 MiB, pre-RLE1 stream 0.9 MB, selectors 32 KiB, segment records ~100 KB.
+ * There is NO CPU fallback: without a usable gfx950 device every entry point fails with MI355X_BZ2_ERR_NO_DEVICE.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355x_bz2.h"
+#include "bz2_kernels.hip.h"
+
+using namespace bz2gpu;
+
+struct mi355x_bz2_ctx
+{
+    int device{ 0 };
+    uint32_t flags{ 0 };
+    hipStream_t stream{ nullptr };
+    std::string lastError;
+    std::mutex mutex;
+
+    /* input */
+    uint8_t* dInOwned{ nullptr };
+    uint64_t dInOwnedCapacity{ 0 };
+    const uint8_t* dIn{ nullptr };
+    uint64_t inSize{ 0 };
+
+    /* per-block scratch, capacity in blocks */
+    uint32_t capacity{ 0 };
+    uint64_t* dOffsets{ nullptr };
+    BlockMeta* dMeta{ nullptr };
+    uint8_t* dSel{ nullptr };
+    uint8_t* dL{ nullptr };
+    uint32_t* dTab{ nullptr };
+    uint8_t* dR{ nullptr };
+    uint32_t* dSegLen{ nullptr };
+    uint32_t* dSegSucc{ nullptr };
+    uint32_t* dSegOff{ nullptr };
+    BlockMeta* hMeta{ nullptr };       /* pinned */
+    uint64_t* hOffsets{ nullptr };     /* pinned */
+
+    /* output */
+    uint8_t* dOut{ nullptr };
+    uint64_t outCapacity{ 0 };
+    uint64_t outSize{ 0 };
+    uint32_t lastBlocks{ 0 };
+
+    CrcConsts crc{};
+    hipEvent_t ev[6]{};
+    mi355x_bz2_timings timings{};
+};
+
+namespace
+{
+uint32_t
+hostGfMul( uint32_t a, uint32_t b )
+{
+    uint32_t r = 0;
+    for ( int i = 31; i >= 0; --i ) {
+        r = ( r << 1 ) ^ ( ( r >> 31 ) ? 0x04C11DB7u : 0u );
+        if ( ( a >> i ) & 1u ) r ^= b;
+    }
+    return r;
+}
+
+void
+initCrcConsts( CrcConsts& cc )
+{
+    /* x^8, squared repeatedly */
+    uint32_t p = 0x100u;
+    for ( int k = 0; k < 32; ++k ) {
+        cc.pow8[k] = p;
+        p = hostGfMul( p, p );
+    }
+    /* x^-1 = x^(2^32 - 2) (P is primitive, the multiplicative group has order 2^32 - 1) */
+    uint32_t xinv = 1u, base = 0x2u;   /* base = x */
+    uint64_t e = 0xFFFFFFFEull;
+    while ( e != 0 ) {
+        if ( e & 1u ) xinv = hostGfMul( xinv, base );
+        base = hostGfMul( base, base );
+        e >>= 1;
+    }
+    uint32_t q = xinv;
+    for ( int i = 0; i < 3; ++i ) q = hostGfMul( q, q );   /* x^-8 */
+    for ( int k = 0; k < 32; ++k ) {
+        cc.ipow8[k] = q;
+        q = hostGfMul( q, q );
+    }
+}
+
+#define HIP_TRY( ctx, expr )                                                                       \
+    do {                                                                                           \
+        const hipError_t err_ = ( expr );                                                          \
+        if ( err_ != hipSuccess ) {                                                                \
+            ( ctx )->lastError = std::string( #expr ) + ": " + hipGetErrorString( err_ );          \
+            return MI355X_BZ2_ERR_DEVICE;                                                          \
+        }                                                                                          \
+    } while ( 0 )
+
+void
+freeScratch( mi355x_bz2_ctx* c )
+{
+    (void)hipFree( c->dOffsets ); c->dOffsets = nullptr;
+    (void)hipFree( c->dMeta ); c->dMeta = nullptr;
+    (void)hipFree( c->dSel ); c->dSel = nullptr;
+    (void)hipFree( c->dL ); c->dL = nullptr;
+    (void)hipFree( c->dTab ); c->dTab = nullptr;
+    (void)hipFree( c->dR ); c->dR = nullptr;
+    (void)hipFree( c->dSegLen ); c->dSegLen = nullptr;
+    (void)hipFree( c->dSegSucc ); c->dSegSucc = nullptr;
+    (void)hipFree( c->dSegOff ); c->dSegOff = nullptr;
+    (void)hipHostFree( c->hMeta ); c->hMeta = nullptr;
+    (void)hipHostFree( c->hOffsets ); c->hOffsets = nullptr;
+    c->capacity = 0;
+}
+
+int
+ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
+{
+    if ( nBlocks <= c->capacity ) return MI355X_BZ2_OK;
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    freeScratch( c );
+    uint32_t cap = 64;
+    while ( cap < nBlocks ) cap *= 2;
+    if ( cap > nBlocks && (uint64_t)cap * TAB_STRIDE * 4 > ( 64ull << 30 ) ) cap = nBlocks;  /* keep large batches tight */
+    HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dMeta, (size_t)cap * sizeof( BlockMeta ) ) );
+    HIP_TRY( c, hipMalloc( &c->dSel, (size_t)cap * SEL_STRIDE ) );
+    HIP_TRY( c, hipMalloc( &c->dL, (size_t)cap * L_STRIDE + 256 ) );
+    HIP_TRY( c, hipMalloc( &c->dTab, (size_t)cap * TAB_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dR, (size_t)cap * L_STRIDE + 256 ) );
+    HIP_TRY( c, hipMalloc( &c->dSegLen, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dSegSucc, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dSegOff, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipHostMalloc( &c->hMeta, (size_t)cap * sizeof( BlockMeta ), hipHostMallocDefault ) );
+    HIP_TRY( c, hipHostMalloc( &c->hOffsets, (size_t)cap * sizeof( uint64_t ), hipHostMallocDefault ) );
+    c->capacity = cap;
+    return MI355X_BZ2_OK;
+}
+
+int
+ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
+{
+    if ( size + 256 <= c->outCapacity ) return MI355X_BZ2_OK;
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    (void)hipFree( c->dOut );
+    c->dOut = nullptr;
+    c->outCapacity = 0;
+    uint64_t cap = size + size / 8 + ( 1u << 20 );
+    HIP_TRY( c, hipMalloc( &c->dOut, cap ) );
+    c->outCapacity = cap;
+    return MI355X_BZ2_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char*
+mi355x_bz2_status_string( int status )
+{
+    switch ( status ) {
+    case MI355X_BZ2_OK: return "OK";
+    case MI355X_BZ2_ERR_EOF: return "end of file reached inside a block";
+    case MI355X_BZ2_ERR_BAD_MAGIC: return "[BZip2 block header] invalid compressed magic";
+    case MI355X_BZ2_ERR_RANDOMIZED: return "[BZip2 block header] deprecated isRandomized bit is not supported";
+    case MI355X_BZ2_ERR_ORIGPTR_RANGE: return "[BZip2 block header] origPtr is larger than buffer size";
+    case MI355X_BZ2_ERR_GROUP_COUNT: return "[BZip2 block header] Invalid Huffman coding group count";
+    case MI355X_BZ2_ERR_SELECTOR_COUNT: return "[BZip2 block header] The number of selectors is invalid";
+    case MI355X_BZ2_ERR_SELECTOR_UNARY: return "[BZip2 block header] Could not find zero termination";
+    case MI355X_BZ2_ERR_CODE_LENGTH: return "[BZip2 block header] start_huffman_length is larger than 20 or zero";
+    case MI355X_BZ2_ERR_HUFFMAN_LENGTHS: return "Invalid Huffman code lengths";
+    case MI355X_BZ2_ERR_SELECTOR_OVERRUN: return "[BZip2 block data] selector out of maximum range";
+    case MI355X_BZ2_ERR_INVALID_CODE: return "[BZip2 block data] no Huffman code matches (bad optional access)";
+    case MI355X_BZ2_ERR_RUN_OVERFLOW: return "[BZip2 block data] dbufCount + hh > dbufSize";
+    case MI355X_BZ2_ERR_DATA_OVERFLOW: return "[BZip2 block data] dbufCount > dbufSize";
+    case MI355X_BZ2_ERR_ORIGPTR_DATA: return "[BZip2 block data] origPtr error";
+    case MI355X_BZ2_ERR_CRC: return "Calculated CRC for block mismatches";
+    case MI355X_BZ2_ERR_STREAM_HEADER: return "Input header is not BZip2 magic string 'BZh' or invalid block size";
+    case MI355X_BZ2_ERR_OUTPUT_CAPACITY: return "output capacity exceeded";
+    case MI355X_BZ2_ERR_DEVICE: return "HIP runtime error";
+    case MI355X_BZ2_ERR_NO_DEVICE: return "no usable MI355X (gfx950) device; there is no CPU fallback";
+    case MI355X_BZ2_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MI355X_BZ2_ERR_IO: return "I/O error";
+    case MI355X_BZ2_ERR_CLOSED: return "operation on closed reader";
+    case MI355X_BZ2_ERR_LOGIC: return "internal logic error";
+    default: return "unknown status";
+    }
+}
+
+int
+mi355x_bz2_abi_version( void )
+{
+    return MI355X_BZ2_ABI_VERSION;
+}
+
+int
+mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
+{
+    if ( out == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if ( hipGetDeviceCount( &count ) != hipSuccess || count <= 0 ) {
+        return MI355X_BZ2_ERR_NO_DEVICE;
+    }
+    int device = config != nullptr ? config->device : -1;
+    if ( device < 0 ) {
+        if ( hipGetDevice( &device ) != hipSuccess ) return MI355X_BZ2_ERR_NO_DEVICE;
+    }
+    if ( device >= count ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop{};
+    if ( hipGetDeviceProperties( &prop, device ) != hipSuccess ) return MI355X_BZ2_ERR_NO_DEVICE;
+    if ( std::strncmp( prop.gcnArchName, "gfx950", 6 ) != 0 ) {
+        return MI355X_BZ2_ERR_NO_DEVICE;   /* kernels are built for gfx950 only */
+    }
+    auto* c = new mi355x_bz2_ctx();
+    c->device = device;
+    c->flags = config != nullptr ? config->flags : 0;
+    if ( hipSetDevice( device ) != hipSuccess
+         || hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
+        delete c;
+        return MI355X_BZ2_ERR_DEVICE;
+    }
+    for ( auto& e : c->ev ) {
+        if ( hipEventCreate( &e ) != hipSuccess ) {
+            delete c;
+            return MI355X_BZ2_ERR_DEVICE;
+        }
+    }
+    initCrcConsts( c->crc );
+    const uint32_t initial = ( config != nullptr && config->max_batch_blocks > 0 ) ? config->max_batch_blocks : 64;
+    const int rc = ensureScratch( c, initial );
+    if ( rc != MI355X_BZ2_OK ) {
+        std::fprintf( stderr, "mi355x_bz2_create: %s\n", c->lastError.c_str() );
+        mi355x_bz2_destroy( c );
+        return rc;
+    }
+    *out = c;
+    return MI355X_BZ2_OK;
+}
+
+void
+mi355x_bz2_destroy( mi355x_bz2_ctx* c )
+{
+    if ( c == nullptr ) return;
+    (void)hipSetDevice( c->device );
+    if ( c->stream ) (void)hipStreamSynchronize( c->stream );
+    freeScratch( c );
+    (void)hipFree( c->dInOwned );
+    (void)hipFree( c->dOut );
+    for ( auto& e : c->ev ) {
+        if ( e ) (void)hipEventDestroy( e );
+    }
+    if ( c->stream ) (void)hipStreamDestroy( c->stream );
+    delete c;
+}
+
+const char*
+mi355x_bz2_last_error( const mi355x_bz2_ctx* c )
+{
+    return c != nullptr ? c->lastError.c_str() : "null context";
+}
+
+int
+mi355x_bz2_set_input_host( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t size )
+{
+    if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    const uint64_t padded = ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256;
+    if ( padded > c->dInOwnedCapacity ) {
+        HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+        (void)hipFree( c->dInOwned );
+        c->dInOwned = nullptr;
+        c->dInOwnedCapacity = 0;
+        HIP_TRY( c, hipMalloc( &c->dInOwned, padded ) );
+        c->dInOwnedCapacity = padded;
+    }
+    HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0, padded - ( size & ~uint64_t( 255 ) ), c->stream ) );
+    if ( size > 0 ) {
+        HIP_TRY( c, hipMemcpyAsync( c->dInOwned, bytes, size, hipMemcpyHostToDevice, c->stream ) );
+    }
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    c->dIn = c->dInOwned;
+    c->inSize = size;
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_t size )
+{
+    if ( c == nullptr || ( deviceBytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    if ( ( reinterpret_cast<uintptr_t>( deviceBytes ) & 3u ) != 0 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    c->dIn = static_cast<const uint8_t*>( deviceBytes );
+    c->inSize = size;
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
+                         mi355x_bz2_block_result* results, uint64_t* totalDecoded )
+{
+    if ( c == nullptr || ( n > 0 && ( offsets == nullptr || results == nullptr ) ) ) {
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    const std::scoped_lock lock( c->mutex );
+    if ( totalDecoded ) *totalDecoded = 0;
+    c->outSize = 0;
+    c->lastBlocks = 0;
+    if ( n == 0 ) return MI355X_BZ2_OK;
+    if ( n > 65535 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    if ( c->dIn == nullptr ) {
+        c->lastError = "no input set";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    int rc = ensureScratch( c, n );
+    if ( rc != MI355X_BZ2_OK ) return rc;
+
+    std::memcpy( c->hOffsets, offsets, (size_t)n * sizeof( uint64_t ) );
+    HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
+
+    HIP_TRY( c, hipEventRecord( c->ev[0], c->stream ) );
+    hipLaunchKernelGGL( k_stage1, dim3( n ), dim3( 64 ), 0, c->stream,
+                        reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dSel, c->dL );
+    HIP_TRY( c, hipEventRecord( c->ev[1], c->stream ) );
+    hipLaunchKernelGGL( k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
+    HIP_TRY( c, hipEventRecord( c->ev[2], c->stream ) );
+    const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );
+    hipLaunchKernelGGL( k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
+                        c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+    hipLaunchKernelGGL( k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
+    hipLaunchKernelGGL( k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
+                        c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+    HIP_TRY( c, hipEventRecord( c->ev[3], c->stream ) );
+    hipLaunchKernelGGL( k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
+    HIP_TRY( c, hipGetLastError() );
+
+    /* sizes -> host: output offsets are an exclusive scan of the decoded sizes (ragged, gap-free) */
+    HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    uint64_t total = 0;
+    for ( uint32_t i = 0; i < n; ++i ) {
+        c->hMeta[i].out_off = total;
+        if ( c->hMeta[i].walk_ok ) total += c->hMeta[i].decoded_size;
+    }
+    rc = ensureOutput( c, total );
+    if ( rc != MI355X_BZ2_OK ) return rc;
+    HIP_TRY( c, hipMemcpyAsync( c->dMeta, c->hMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) );
+    hipLaunchKernelGGL( k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
+    hipLaunchKernelGGL( k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
+    HIP_TRY( c, hipEventRecord( c->ev[4], c->stream ) );
+    HIP_TRY( c, hipGetLastError() );
+    HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+
+    for ( uint32_t i = 0; i < n; ++i ) {
+        const BlockMeta& m = c->hMeta[i];
+        mi355x_bz2_block_result& r = results[i];
+        r.encoded_offset_bits = m.enc_off;
+        r.encoded_size_bits = m.enc_size;
+        r.decoded_size = m.status == ST_OK || m.status == ST_CRC ? m.decoded_size : 0;
+        r.data_offset = m.out_off;
+        r.header_crc = m.header_crc;
+        r.computed_crc = m.computed_crc;
+        r.bwt_length = m.n;
+        r.orig_ptr = m.orig_ptr;
+        r.n_symbols = m.nsym;
+        r.is_eos = m.is_eos;
+        r.is_eof = m.is_eof;
+        r.status = m.status;
+    }
+    c->outSize = total;
+    c->lastBlocks = n;
+    if ( totalDecoded ) *totalDecoded = total;
+
+    float ms = 0;
+    c->timings = {};
+    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[4] ) == hipSuccess ) c->timings.ms_total = ms;
+    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[1] ) == hipSuccess ) c->timings.ms_huffman = ms;
+    if ( hipEventElapsedTime( &ms, c->ev[1], c->ev[2] ) == hipSuccess ) c->timings.ms_bwt_build = ms;
+    if ( hipEventElapsedTime( &ms, c->ev[2], c->ev[3] ) == hipSuccess ) c->timings.ms_walk = ms;
+    if ( hipEventElapsedTime( &ms, c->ev[3], c->ev[4] ) == hipSuccess ) c->timings.ms_rle_crc = ms;
+    return MI355X_BZ2_OK;
+}
+
+const void*
+mi355x_bz2_output_device( const mi355x_bz2_ctx* c )
+{
+    return c != nullptr ? c->dOut : nullptr;
+}
+
+int
+mi355x_bz2_copy_output( mi355x_bz2_ctx* c, uint64_t offset, uint64_t size, void* hostDst )
+{
+    if ( c == nullptr || ( hostDst == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( offset + size > c->outSize ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    if ( size == 0 ) return MI355X_BZ2_OK;
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    HIP_TRY( c, hipMemcpyAsync( hostDst, c->dOut + offset, size, hipMemcpyDeviceToHost, c->stream ) );
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_last_timings( const mi355x_bz2_ctx* c, mi355x_bz2_timings* t )
+{
+    if ( c == nullptr || t == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    *t = c->timings;
+    return MI355X_BZ2_OK;
+}
+
+void*
+mi355x_bz2_stream( const mi355x_bz2_ctx* c )
+{
+    return c != nullptr ? static_cast<void*>( c->stream ) : nullptr;
+}
+
+int
+mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* c, uint32_t index, int stage, void* hostDst, uint64_t capacity )
+{
+    if ( c == nullptr || hostDst == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( index >= c->lastBlocks ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const uint64_t N = c->hMeta[index].n;
+    const void* src = nullptr;
+    uint64_t bytes = 0;
+    switch ( stage ) {
+    case 0: src = c->dL + (size_t)index * L_STRIDE; bytes = N; break;
+    case 1: src = c->dTab + (size_t)index * TAB_STRIDE; bytes = N * 4; break;
+    case 2: src = c->dR + (size_t)index * L_STRIDE; bytes = N; break;
+    default: return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    if ( bytes > capacity ) bytes = capacity;
+    if ( bytes == 0 ) return MI355X_BZ2_OK;
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    HIP_TRY( c, hipMemcpyAsync( hostDst, src, bytes, hipMemcpyDeviceToHost, c->stream ) );
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    return MI355X_BZ2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1013 @@
+/**
+ * bz2_kernels.hip.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the bzip2 block-decode hot path.
+ *
+ * Pipeline for one batch of independent bzip2 blocks (reference: one BZ2BlockFetcher::decodeBlock call per block,
+ * src/indexed_bzip2/BZ2BlockFetcher.hpp:85-138):
+ *
+ *   k_stage1      one wavefront per block: block header, symbol map, selectors, code lengths, canonical Huffman
+ *                 LUTs in LDS, Huffman + RUNA/RUNB + MTF decode -> L column (u8[N])      bzip2.hpp:479-807
+ *   k_bwt_build   per block: byte histogram, stable ranks -> packed LF table u32[N] = LF<<8 | byte | MARK
+ *                 (coalesced writes; replaces the scatter of prepare(), bzip2.hpp:810-847)
+ *   k_walk<false> one lane per SEGMENT of the permutation cycle: length + successor     } multi-start form of the
+ *   k_link        orders the segments starting at origPtr, prefix sums their lengths    } N-step dependent walk of
+ *   k_walk<true>  walks each segment again and writes the pre-RLE1 bytes in order       } bzip2.hpp:872-879
+ *   k_rle<false>  RLE1 as a 5-state scan: decoded size D per block                      bzip2.hpp:881-896
+ *   k_rle<true>   expansion into the batch output buffer
+ *   k_crc         bzip2 CRC-32 of the D bytes by chunk CRCs + GF(2) shift-combine        bzip2.hpp:59-91, 900-907
+ *
+ * All arithmetic is integer/byte work bounded by HBM traffic and load latency; there is no MFMA anywhere.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bz2gpu
+{
+constexpr uint32_t MAX_N = 900000;            /* bzip2.hpp:416 dbuf size */
+constexpr uint32_t L_STRIDE = 900096;         /* bytes per block in the L and R buffers (multiple of 256) */
+constexpr uint32_t SEL_STRIDE = 32768;        /* bzip2.hpp:451 */
+constexpr uint32_t TAB_STRIDE = 1u << 20;     /* u32 entries per block: every 20-bit index stays in bounds */
+constexpr uint32_t KMAX = 8192;               /* max regular walk segments per block */
+constexpr uint32_t SEG_STRIDE = KMAX + 64;
+constexpr uint32_t MIN_SEG_STRIDE = 32;
+constexpr int LUT_BITS = 10;
+constexpr uint32_t MARK = 0x80000000u;
+constexpr uint32_t LF_MASK = 0xFFFFFu;
+constexpr uint32_t INVALID_OFF = 0xFFFFFFFFu;
+
+enum Status : int32_t {
+    ST_OK = 0, ST_EOF = 1, ST_BAD_MAGIC = 2, ST_RANDOMIZED = 3, ST_ORIGPTR_RANGE = 4, ST_GROUP_COUNT = 5,
+    ST_SELECTOR_COUNT = 6, ST_SELECTOR_UNARY = 7, ST_CODE_LENGTH = 8, ST_HUFFMAN_LENGTHS = 9,
+    ST_SELECTOR_OVERRUN = 10, ST_INVALID_CODE = 11, ST_RUN_OVERFLOW = 12, ST_DATA_OVERFLOW = 13,
+    ST_ORIGPTR_DATA = 14, ST_CRC = 15
+};
+
+/** Device-side per-block record. */
+struct BlockMeta
+{
+    uint64_t enc_off;
+    uint64_t enc_size;
+    uint64_t decoded_size;
+    uint64_t out_off;
+    uint32_t header_crc;
+    uint32_t computed_crc;
+    uint32_t n;          /* BWT length N */
+    uint32_t orig_ptr;
+    uint32_t nsym;
+    int32_t  is_eos;
+    int32_t  is_eof;
+    int32_t  status;
+    uint32_t seg_stride;
+    uint32_t nseg;
+    uint32_t walk_ok;    /* 1 if stages >= walk should run */
+    uint32_t pad;
+};
+
+struct CrcConsts
+{
+    uint32_t pow8[32];    /* x^(8*2^k) mod P */
+    uint32_t ipow8[32];   /* x^(-8*2^k) mod P */
+};
+
+__device__ __forceinline__ uint32_t
+sfl( uint32_t v )
+{
+    return __builtin_amdgcn_readfirstlane( v );
+}
+
+__device__ __forceinline__ uint32_t
+lane_id()
+{
+    return threadIdx.x & 63u;
+}
+
+/* -------------------------------------------------------------------------------------------------------------
+ * MSB-first bit reader over big-endian-interpreted 32-bit words (reference: BitReader<true,uint64_t>,
+ * src/core/BitReader.hpp:190-290, 469-476).  All state is wave-uniform and ends up in SGPRs.
+ * ------------------------------------------------------------------------------------------------------------- */
+struct BitRd
+{
+    const uint32_t* w;
+    uint64_t nwords;
+    uint64_t size_bits;
+    uint32_t tail_mask;
+    uint64_t buf;     /* valid bits left-aligned */
+    uint32_t n;       /* number of valid bits in buf */
+    uint64_t widx;    /* next word to load */
+    uint64_t pos;     /* absolute bit position of buf's first bit */
+    bool eof;
+
+    __device__ __forceinline__ uint32_t
+    loadw( uint64_t i ) const
+    {
+        uint32_t v = 0;
+        if ( i < nwords ) {
+            v = __builtin_bswap32( sfl( w[i] ) );
+            if ( i == nwords - 1 ) {
+                v &= tail_mask;
+            }
+        }
+        return v;
+    }
+
+    __device__ __forceinline__ void
+    init( const uint32_t* words, uint64_t size_bytes, uint64_t bitpos )
+    {
+        w = words;
+        nwords = ( size_bytes + 3 ) >> 2;
+        size_bits = size_bytes * 8;
+        const uint32_t r = (uint32_t)( size_bytes & 3 );
+        tail_mask = r == 0 ? 0xFFFFFFFFu : ( 0xFFFFFFFFu << ( 32 - 8 * r ) );
+        pos = bitpos;
+        eof = false;
+        widx = bitpos >> 5;
+        const uint32_t sh = (uint32_t)( bitpos & 31 );
+        const uint64_t hi = loadw( widx ), lo = loadw( widx + 1 );
+        buf = ( ( hi << 32 ) | lo ) << sh;
+        n = 64 - sh;
+        widx += 2;
+    }
+
+    /** Guarantees n > 32 afterwards. */
+    __device__ __forceinline__ void
+    refill()
+    {
+        if ( n <= 32 ) {
+            buf |= (uint64_t)loadw( widx ) << ( 32 - n );
+            n += 32;
+            ++widx;
+        }
+    }
+
+    __device__ __forceinline__ uint32_t
+    peek( uint32_t k ) const   /* 1 <= k <= 32, k <= n */
+    {
+        return (uint32_t)( buf >> ( 64 - k ) );
+    }
+
+    __device__ __forceinline__ void
+    skip( uint32_t k )
+    {
+        buf <<= k;
+        n -= k;
+        pos += k;
+    }
+
+    /** read k <= 32 bits; sets eof (sticky) if the read crosses the end of the input. */
+    __device__ __forceinline__ uint32_t
+    read( uint32_t k )
+    {
+        refill();
+        if ( pos + k > size_bits ) {
+            eof = true;
+        }
+        const uint32_t v = peek( k );
+        skip( k );
+        return v;
+    }
+};
+
+/* -------------------------------------------------------------------------------------------------------------
+ * Wave-cooperative move-to-front list: 256 entries, 4 per lane (entry 4*lane+k in byte k), held in one VGPR.
+ * One literal costs a handful of VALU/DPP instructions independent of the index (the reference memmoves up to
+ * 255 bytes, bzip2.hpp:781-785).  The list is initialised with symbolToByte so the value IS the output byte.
+ * ------------------------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t
+mtf_step( uint32_t& m, uint32_t ii /* wave-uniform, 1..255 */, uint32_t lane )
+{
+    const uint32_t q = ii >> 2;
+    const uint32_t r = ii & 3;
+    const uint32_t mq = __builtin_amdgcn_readlane( m, q );
+    const uint32_t x = ( mq >> ( 8 * r ) ) & 0xFFu;
+    /* up[j] = m[j-1] (wave shift right by one lane) */
+    const uint32_t up = __builtin_amdgcn_update_dpp( 0u, m, 0x138 /* wave_shr:1 */, 0xF, 0xF, false );
+    const uint32_t carry = lane == 0 ? x : ( up >> 24 );
+    const uint32_t shifted = ( m << 8 ) | carry;
+    const uint32_t keep = r == 3 ? 0u : ( 0xFFFFFFFFu << ( 8 * ( r + 1 ) ) );
+    const uint32_t partial = ( shifted & ~keep ) | ( m & keep );
+    m = lane < q ? shifted : ( lane == q ? partial : m );
+    return x;
+}
+
+/** Lanes whose `key` (low `bits` bits) equals this lane's, restricted to `valid` lanes. */
+__device__ __forceinline__ uint64_t
+match_any( uint32_t key, int bits, bool valid )
+{
+    uint64_t mask = __ballot( valid );
+    for ( int b = 0; b < bits; ++b ) {
+        const bool bit = ( key >> b ) & 1u;
+        const uint64_t bal = __ballot( bit );
+        mask &= bit ? bal : ~bal;
+    }
+    return mask;
+}
+
+__device__ __forceinline__ uint32_t
+popc_below( uint64_t mask, uint32_t lane )
+{
+    return __popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+}
+
+/* =============================================================================================================
+ * k_stage1: one wavefront (64 threads) per bzip2 block.
+ * ============================================================================================================= */
+struct Stage1Shared
+{
+    uint16_t lut[6][1 << LUT_BITS];   /* {len:5, sym:9}; 0 = not a short code */
+    uint16_t perm[6][260];            /* symbols sorted by (length, symbol): m_symbolsPerLength */
+    uint32_t first[6][24];            /* m_minimumCodeValuesPerLevel, indexed by length */
+    uint32_t count[6][24];            /* code-length frequencies */
+    uint32_t offs[6][24];             /* m_offsets, indexed by length */
+    uint32_t running[24];
+    uint8_t  lens[6][264];
+    uint16_t bitmap[16];
+    uint8_t  sym_to_byte[256];
+    uint32_t minmax[6];               /* minLen | maxLen << 8 */
+};
+
+__global__ __launch_bounds__( 64 ) void
+k_stage1( const uint32_t* __restrict__ in_words,
+          uint64_t                     in_size_bytes,
+          const uint64_t* __restrict__ offsets,
+          BlockMeta* __restrict__      meta,
+          uint8_t*                     sel_buf,
+          uint8_t* __restrict__        l_buf )
+{
+    __shared__ Stage1Shared sh;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
+    uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
+
+    const uint64_t start = offsets[b];
+    BitRd br;
+    br.init( in_words, in_size_bytes, start );
+
+    int32_t status = ST_OK;
+    uint32_t headerCrc = 0, origPtr = 0, N = 0, nsym = 0;
+    int32_t isEos = 0, isEof = 0;
+    uint64_t encSize = 0;
+    uint32_t symbolCount = 0, groupCount = 0, nSel = 0;
+
+#define FAIL( code ) do { status = br.eof ? (int32_t)ST_EOF : (int32_t)( code ); goto finish; } while ( 0 )
+
+    /* ---- Block::readBlockHeader, bzip2.hpp:479-523 ---- */
+    if ( start > br.size_bits ) {
+        br.eof = true;
+        FAIL( ST_EOF );
+    }
+    {
+        const uint64_t hi = br.read( 24 );
+        const uint64_t lo = br.read( 24 );
+        const uint64_t magic = ( hi << 24 ) | lo;
+        headerCrc = br.read( 32 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( magic == 0x177245385090ULL ) {
+            isEos = 1;
+            const uint32_t inByte = (uint32_t)( br.pos & 7 );
+            if ( inByte > 0 ) {
+                br.read( 8 - inByte );
+                if ( br.eof ) FAIL( ST_EOF );
+            }
+            encSize = br.pos - start;
+            isEof = br.pos >= br.size_bits;
+            goto finish;
+        }
+        if ( magic != 0x314159265359ULL ) FAIL( ST_BAD_MAGIC );
+        const uint32_t randomized = br.read( 1 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( randomized ) FAIL( ST_RANDOMIZED );
+        origPtr = br.read( 24 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( origPtr > MAX_N ) FAIL( ST_ORIGPTR_RANGE );
+    }
+
+    /* ---- Block::readSymbolMaps, bzip2.hpp:526-571 ---- */
+    {
+        const uint32_t used = br.read( 16 );
+        for ( uint32_t v = lane; v < 256; v += 64 ) sh.sym_to_byte[v] = 0;   /* fresh Block: zero-initialised */
+        for ( int i = 0; i < 16; ++i ) {
+            uint32_t bm = 0;
+            if ( used & ( 1u << ( 15 - i ) ) ) {
+                bm = br.read( 16 );
+            }
+            if ( lane == 0 ) sh.bitmap[i] = (uint16_t)bm;
+        }
+        __syncthreads();
+        uint32_t total = 0;
+        for ( int g = 0; g < 16; ++g ) total += __popc( sh.bitmap[g] );
+        symbolCount = total;
+        for ( uint32_t v = lane; v < 256; v += 64 ) {
+            const uint32_t g = v >> 4, j = v & 15;
+            const uint32_t bm = sh.bitmap[g];
+            if ( bm & ( 1u << ( 15 - j ) ) ) {
+                uint32_t rank = 0;
+                for ( uint32_t gg = 0; gg < g; ++gg ) rank += __popc( sh.bitmap[gg] );
+                rank += j == 0 ? 0 : __popc( bm >> ( 16 - j ) );
+                sh.sym_to_byte[rank] = (uint8_t)v;
+            }
+        }
+        __syncthreads();
+        if ( br.eof ) FAIL( ST_EOF );
+    }
+
+    /* ---- Block::readSelectors, bzip2.hpp:574-637 ---- */
+    {
+        groupCount = br.read( 3 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( groupCount < 2 || groupCount > 6 ) FAIL( ST_GROUP_COUNT );
+        nSel = br.read( 15 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( nSel == 0 ) FAIL( ST_SELECTOR_COUNT );
+        uint32_t mtfsel = 0x543210u;   /* nibble k = entry k */
+        uint32_t packed = 0;
+        for ( uint32_t i = 0; i < nSel; ++i ) {
+            br.refill();
+            if ( br.pos + 6 > br.size_bits ) {   /* peek<6> throws at EOF, BitReader.hpp:458-460 */
+                br.eof = true;
+                FAIL( ST_EOF );
+            }
+            const uint32_t bits6 = br.peek( 6 );
+            const uint32_t j = __clz( ~( bits6 << 26 ) );   /* leading ones, 6 if all set */
+            br.skip( j + 1 );
+            if ( j >= groupCount ) FAIL( ST_SELECTOR_UNARY );
+            const uint32_t shj = 4 * j;
+            const uint32_t val = ( mtfsel >> shj ) & 0xFu;
+            const uint32_t low = mtfsel & ( ( 1u << shj ) - 1u );
+            const uint32_t highMask = ~( ( 16u << shj ) - 1u );
+            mtfsel = ( mtfsel & highMask ) | ( low << 4 ) | val;
+            packed |= val << ( 8 * ( i & 3 ) );
+            if ( ( i & 3 ) == 3 || i + 1 == nSel ) {
+                if ( lane == 0 ) *reinterpret_cast<uint32_t*>( sel + ( i & ~3u ) ) = packed;
+                packed = 0;
+            }
+        }
+    }
+
+    /* ---- Block::readTrees, bzip2.hpp:644-685 ---- */
+    {
+        const uint32_t symCount = symbolCount + 2;
+        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            uint32_t hh = br.read( 5 );
+            if ( br.eof ) FAIL( ST_EOF );
+            for ( uint32_t s = 0; s < symCount; ++s ) {
+                for ( ;; ) {
+                    if ( hh - 1u > 19u ) FAIL( ST_CODE_LENGTH );
+                    br.refill();
+                    const uint32_t b2 = br.peek( 2 );
+                    if ( b2 < 2 ) {
+                        if ( br.pos + 1 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+                        br.skip( 1 );
+                        break;
+                    }
+                    if ( br.pos + 2 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+                    hh += b2 == 2 ? 1u : 0xFFFFFFFFu;
+                    br.skip( 2 );
+                }
+                if ( lane == 0 ) sh.lens[t][s] = (uint8_t)hh;
+            }
+        }
+        __syncthreads();
+
+        /* ---- canonical Huffman tables: HuffmanCodingBase.hpp:46-149, HuffmanCodingSymbolsPerLength.hpp:41-95,
+         *      HuffmanCodingShortBitsCached.hpp:39-96 (the LUT) ---- */
+        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            /* length frequencies: lane l counts symbols of length l */
+            uint32_t c = 0;
+            if ( lane >= 1 && lane <= 20 ) {
+                for ( uint32_t s = 0; s < symCount; ++s ) c += sh.lens[t][s] == lane;
+            }
+            if ( lane < 24 ) sh.count[t][lane] = c;
+            __syncthreads();
+            uint32_t minLen = 0, maxLen = 0;
+            for ( uint32_t l = 1; l <= 20; ++l ) {
+                if ( sh.count[t][l] != 0 ) {
+                    if ( minLen == 0 ) minLen = l;
+                    maxLen = l;
+                }
+            }
+            /* checkCodeLengthFrequencies (CHECK_OPTIMALITY = false): reject over-subscribed length sets */
+            {
+                uint32_t unused = 1u << minLen;
+                bool bad = false;
+                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
+                    const uint32_t f = sh.count[t][l];
+                    if ( f > unused ) { bad = true; break; }
+                    unused = ( unused - f ) * 2u;
+                }
+                if ( bad ) FAIL( ST_HUFFMAN_LENGTHS );
+            }
+            /* minimum code value and symbol offset per length */
+            if ( lane == 0 ) {
+                uint32_t minCode = 0, sum = 0;
+                for ( uint32_t l = 0; l < 24; ++l ) { sh.first[t][l] = 0; sh.offs[t][l] = 0; }
+                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
+                    minCode = ( minCode + ( l > minLen ? sh.count[t][l - 1] : 0u ) ) << 1;
+                    if ( l == minLen ) minCode = 0;
+                    sh.first[t][l] = minCode;
+                    sh.offs[t][l] = sum;
+                    sh.running[l] = sum;
+                    sum += sh.count[t][l];
+                }
+                sh.minmax[t] = minLen | ( maxLen << 8 );
+            }
+            __syncthreads();
+            /* symbols sorted by (length, symbol index): stable multi-split, 64 symbols per step */
+            for ( uint32_t base = 0; base < symCount; base += 64 ) {
+                const uint32_t s = base + lane;
+                const bool valid = s < symCount;
+                const uint32_t len = valid ? sh.lens[t][s] : 0u;
+                const uint64_t same = match_any( len, 5, valid );
+                const uint32_t rank = popc_below( same, lane );
+                uint32_t basePos = 0;
+                if ( valid ) basePos = sh.running[len];
+                if ( valid ) sh.perm[t][basePos + rank] = (uint16_t)s;
+                __syncthreads();
+                if ( valid && rank == 0 ) sh.running[len] = basePos + (uint32_t)__popcll( same );
+                __syncthreads();
+            }
+            /* LUT: every LUT_BITS-bit prefix -> {len, sym} of the code it starts with (0 if longer / none) */
+            const uint32_t lutMax = maxLen < (uint32_t)LUT_BITS ? maxLen : (uint32_t)LUT_BITS;
+            for ( uint32_t e = lane; e < ( 1u << LUT_BITS ); e += 64 ) {
+                uint32_t val = 0;
+                for ( uint32_t l = minLen; l <= lutMax; ++l ) {
+                    const uint32_t code = e >> ( LUT_BITS - l );
+                    const uint32_t d = code - sh.first[t][l];
+                    if ( d < sh.count[t][l] ) {
+                        val = l | ( (uint32_t)sh.perm[t][sh.offs[t][l] + d] << 5 );
+                        break;
+                    }
+                }
+                sh.lut[t][e] = (uint16_t)val;
+            }
+            __syncthreads();
+        }
+    }
+
+    /* ---- Block::readBlockData, bzip2.hpp:691-807: Huffman + RUNA/RUNB + MTF -> L ---- */
+    {
+        uint32_t m;   /* MTF list, 4 entries per lane, pre-mapped through symbolToByte */
+        {
+            const uint32_t* s2b = reinterpret_cast<const uint32_t*>( sh.sym_to_byte );
+            m = s2b[lane];
+        }
+        uint32_t groupLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
+        uint32_t runPos = 0, hh = 0, cnt = 0;
+        for ( ;; ) {
+            if ( groupLeft == 0 ) {
+                if ( selIdx >= nSel ) FAIL( ST_SELECTOR_OVERRUN );
+                tcur = sfl( (uint32_t)sel[selIdx] );
+                ++selIdx;
+                groupLeft = 50;
+                tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
+            }
+            --groupLeft;
+            br.refill();
+            const uint32_t idx = br.peek( LUT_BITS );
+            const uint32_t e = sfl( (uint32_t)sh.lut[tcur][idx] );
+            uint32_t len, sym;
+            if ( e != 0 ) {
+                len = e & 31u;
+                sym = e >> 5;
+            } else {
+                /* decodeLong, HuffmanCodingShortBitsCached.hpp:117-150 */
+                len = 0;
+                sym = 0;
+                for ( uint32_t l = LUT_BITS + 1; l <= tMaxLen; ++l ) {
+                    const uint32_t code = br.peek( l );
+                    const uint32_t d = code - sfl( sh.first[tcur][l] );
+                    if ( d < sfl( sh.count[tcur][l] ) ) {
+                        sym = sfl( (uint32_t)sh.perm[tcur][sfl( sh.offs[tcur][l] ) + d] );
+                        len = l;
+                        break;
+                    }
+                }
+                if ( len == 0 ) {
+                    if ( br.pos + tMaxLen > br.size_bits ) br.eof = true;
+                    FAIL( ST_INVALID_CODE );
+                }
+            }
+            br.skip( len );
+            if ( br.pos > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+            ++nsym;
+
+            if ( sym <= 1 ) {   /* RUNA / RUNB, bzip2.hpp:726-743 */
+                if ( runPos == 0 ) { runPos = 1; hh = 0; }
+                hh += runPos << sym;
+                runPos <<= 1;
+                continue;
+            }
+            if ( runPos != 0 ) {
+                runPos = 0;
+                /* the reference adds in uint32 (wraps, then overruns its buffer); any wrap is an overflow here */
+                if ( (uint64_t)cnt + hh > MAX_N ) FAIL( ST_RUN_OVERFLOW );
+                const uint32_t uc = sfl( m ) & 0xFFu;
+                for ( uint32_t i = lane; i < hh; i += 64 ) L[cnt + i] = (uint8_t)uc;
+                cnt += hh;
+            }
+            if ( sym > symbolCount ) break;   /* end of block */
+            if ( cnt >= MAX_N ) FAIL( ST_DATA_OVERFLOW );
+            const uint32_t x = mtf_step( m, sym - 1, lane );
+            if ( lane == 0 ) L[cnt] = (uint8_t)x;
+            ++cnt;
+        }
+        N = cnt;
+        if ( origPtr >= N ) FAIL( ST_ORIGPTR_DATA );
+        encSize = br.pos - start;
+    }
+
+finish:
+#undef FAIL
+    if ( lane == 0 ) {
+        BlockMeta mt;
+        mt.enc_off = start;
+        mt.enc_size = encSize;
+        mt.decoded_size = 0;
+        mt.out_off = 0;
+        mt.header_crc = headerCrc;
+        mt.computed_crc = 0xFFFFFFFFu;   /* BlockData::calculatedCRC default */
+        mt.n = N;
+        mt.orig_ptr = origPtr;
+        mt.nsym = nsym;
+        mt.is_eos = isEos;
+        mt.is_eof = isEof;
+        mt.status = status;
+        uint32_t stride = ( N + KMAX - 1 ) / KMAX;
+        if ( stride < MIN_SEG_STRIDE ) stride = MIN_SEG_STRIDE;
+        const uint32_t k0 = ( N + stride - 1 ) / stride;
+        mt.seg_stride = stride;
+        mt.nseg = k0 + ( ( N > 0 && origPtr % stride != 0 ) ? 1u : 0u );
+        mt.walk_ok = ( status == ST_OK && !isEos && N > 0 ) ? 1u : 0u;
+        mt.pad = 0;
+        meta[b] = mt;
+    }
+}
+
+/* =============================================================================================================
+ * k_bwt_build: LF[i] = C[L[i]] + rank(L[i], i), written coalesced at i as (LF << 8) | L[i] | MARK.
+ * The reference scatters i into dbuf[C[c]++] (the inverse permutation T) and walks forward (bzip2.hpp:817-831);
+ * LF = T^-1 needs no scatter and is walked backwards from origPtr: out[N-1-k] = L[LF^k(origPtr)].
+ * One workgroup of 1024 threads (16 waves) per block; wave w owns a contiguous 1/16 of the block.
+ * ============================================================================================================= */
+constexpr int BWT_WAVES = 16;
+
+__global__ __launch_bounds__( 1024 ) void
+k_bwt_build( const BlockMeta* __restrict__ meta,
+             const uint8_t* __restrict__   l_buf,
+             uint32_t* __restrict__        tab_buf )
+{
+    __shared__ uint32_t hist[BWT_WAVES][256];
+    __shared__ uint32_t tot[256];
+    const uint32_t b = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t N = mt.n, origPtr = mt.orig_ptr, stride = mt.seg_stride;
+    const uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
+    uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    uint32_t chunk = ( N + BWT_WAVES - 1 ) / BWT_WAVES;
+    chunk = ( chunk + 255u ) & ~255u;
+    const uint32_t begin = wave * chunk < N ? wave * chunk : N;
+    const uint32_t end = begin + chunk < N ? begin + chunk : N;
+
+    for ( uint32_t i = tid; i < BWT_WAVES * 256; i += 1024 ) ( &hist[0][0] )[i] = 0;
+    __syncthreads();
+
+    /* pass 1: per-wave byte histograms (4 bytes per lane per step; L buffer is padded to L_STRIDE) */
+    for ( uint32_t base = begin; base < end; base += 256 ) {
+        const uint32_t i = base + 4 * lane;
+        if ( i < end ) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>( L + i );
+            const uint32_t nb = end - i < 4 ? end - i : 4;
+            for ( uint32_t k = 0; k < nb; ++k ) atomicAdd( &hist[wave][( v >> ( 8 * k ) ) & 0xFF], 1u );
+        }
+    }
+    __syncthreads();
+    if ( tid < 256 ) {
+        uint32_t run = 0;
+        for ( int w = 0; w < BWT_WAVES; ++w ) {
+            const uint32_t t = hist[w][tid];
+            hist[w][tid] = run;
+            run += t;
+        }
+        tot[tid] = run;
+    }
+    __syncthreads();
+    if ( tid < 64 ) {
+        /* exclusive scan of 256 totals: 4 per lane + wave scan */
+        uint32_t v0 = tot[4 * tid], v1 = tot[4 * tid + 1], v2 = tot[4 * tid + 2], v3 = tot[4 * tid + 3];
+        const uint32_t s = v0 + v1 + v2 + v3;
+        uint32_t incl = s;
+        for ( int d = 1; d < 64; d <<= 1 ) {
+            const uint32_t o = __shfl_up( incl, d );
+            if ( (int)tid >= d ) incl += o;
+        }
+        uint32_t excl = incl - s;
+        tot[4 * tid] = excl; excl += v0;
+        tot[4 * tid + 1] = excl; excl += v1;
+        tot[4 * tid + 2] = excl; excl += v2;
+        tot[4 * tid + 3] = excl;
+    }
+    __syncthreads();
+    if ( tid < 256 ) {
+        const uint32_t c = tot[tid];
+        for ( int w = 0; w < BWT_WAVES; ++w ) hist[w][tid] += c;
+    }
+    __syncthreads();
+
+    /* pass 2: stable ranks, 64 positions per wave step */
+    for ( uint32_t base = begin; base < end; base += 64 ) {
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        const uint32_t key = valid ? L[i] : 0u;
+        const uint64_t same = match_any( key, 8, valid );
+        const uint32_t rank = popc_below( same, lane );
+        uint32_t basePos = 0;
+        if ( valid ) basePos = hist[wave][key];
+        if ( valid ) {
+            const uint32_t lf = basePos + rank;
+            const bool mark = ( i % stride == 0 ) || ( i == origPtr );
+            tab[i] = ( lf << 8 ) | key | ( mark ? MARK : 0u );
+            if ( rank == 0 ) hist[wave][key] = basePos + (uint32_t)__popcll( same );
+        }
+    }
+}
+
+/* =============================================================================================================
+ * k_walk: the N-step dependent chain of bzip2.hpp:872-879 cut into <= KMAX+1 independent segments.
+ * Segment starts (MARKed table entries) are every `stride`-th index plus origPtr.  Because LF is a permutation
+ * every walk returns to a marked entry, so each lane terminates after at most N steps.
+ *   EMIT=false: record segment length and successor segment.
+ *   EMIT=true : write the bytes of the segment at their final position in the pre-RLE1 stream R.
+ * ============================================================================================================= */
+__device__ __forceinline__ uint32_t
+seg_start( uint32_t j, uint32_t k0, uint32_t stride, uint32_t origPtr )
+{
+    return j < k0 ? j * stride : origPtr;
+}
+
+template<bool EMIT>
+__global__ __launch_bounds__( 256 ) void
+k_walk( const BlockMeta* __restrict__ meta,
+        const uint32_t* __restrict__  tab_buf,
+        uint32_t*                     seg_len,
+        uint32_t*                     seg_succ,
+        const uint32_t*               seg_off,
+        uint8_t*                      r_buf )
+{
+    const uint32_t b = blockIdx.y;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if ( j >= mt.nseg ) return;
+    const uint32_t N = mt.n, stride = mt.seg_stride, origPtr = mt.orig_ptr;
+    const uint32_t k0 = ( N + stride - 1 ) / stride;
+    const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+    const size_t sidx = (size_t)b * SEG_STRIDE + j;
+
+    uint32_t p = seg_start( j, k0, stride, origPtr );
+    uint32_t e = tab[p];
+    uint32_t len = 0;
+    if constexpr ( EMIT ) {
+        const uint32_t off = seg_off[sidx];
+        if ( off == INVALID_OFF ) return;
+        uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
+        uint32_t pos = N - 1 - off;
+        do {
+            R[pos] = (uint8_t)e;
+            --pos;
+            ++len;
+            p = ( e >> 8 ) & LF_MASK;
+            e = tab[p];
+        } while ( !( e & MARK ) && len < N );
+    } else {
+        do {
+            ++len;
+            p = ( e >> 8 ) & LF_MASK;
+            e = tab[p];
+        } while ( !( e & MARK ) && len < N );
+        seg_len[sidx] = len;
+        const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
+        seg_succ[sidx] = ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu;
+    }
+}
+
+/* =============================================================================================================
+ * k_link: order the segments along the cycle starting at origPtr and prefix-sum their lengths.
+ * A valid block is one N-cycle, so the chain visits every segment once and the lengths sum to N; anything else
+ * (corrupt data that still Huffman-decoded) cannot match its CRC in the reference either -> ST_CRC.
+ * ============================================================================================================= */
+__global__ __launch_bounds__( 256 ) void
+k_link( BlockMeta*                   meta,
+        const uint32_t* __restrict__ seg_len,
+        const uint32_t* __restrict__ seg_succ,
+        uint32_t* __restrict__       seg_off )
+{
+    __shared__ uint32_t slen[SEG_STRIDE];
+    __shared__ uint16_t ssucc[SEG_STRIDE];
+    const uint32_t b = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t nseg = mt.nseg, N = mt.n, stride = mt.seg_stride, origPtr = mt.orig_ptr;
+    const uint32_t k0 = ( N + stride - 1 ) / stride;
+    const size_t base = (size_t)b * SEG_STRIDE;
+    for ( uint32_t j = threadIdx.x; j < nseg; j += 256 ) {
+        slen[j] = seg_len[base + j];
+        const uint32_t s = seg_succ[base + j];
+        ssucc[j] = (uint16_t)( s < nseg ? s : 0xFFFFu );
+        seg_off[base + j] = INVALID_OFF;
+    }
+    __syncthreads();
+    if ( threadIdx.x == 0 ) {
+        const uint32_t first = ( origPtr % stride != 0 ) ? k0 : origPtr / stride;
+        uint32_t cur = first, off = 0, visited = 0;
+        bool ok = true;
+        do {
+            seg_off[base + cur] = off;
+            off += slen[cur];
+            cur = ssucc[cur];
+            ++visited;
+            if ( cur == 0xFFFFu || visited > nseg || off > N ) { ok = false; break; }
+        } while ( cur != first );
+        if ( !ok || off != N ) {
+            meta[b].status = ST_CRC;
+            meta[b].walk_ok = 0;
+        }
+    }
+}
+
+/* =============================================================================================================
+ * k_rle: RLE1 expansion (bzip2.hpp:881-896) as a scan over a 5-state machine.
+ * State k before byte i = number of equal data bytes ending at i-1 (1..4; 4: byte i is a repeat count) or 0 after
+ * a count byte.  With eq_i = (b[i] == b[i-1]):  eq: k -> (k+1) mod 5;  !eq: k -> (k == 4 ? 0 : 1).
+ * Functions {0..4}->{0..4} are packed 3 bits per entry and composed associatively, so the state before every
+ * chunk is an exclusive scan.  Output sizes are a second (sum) scan.  One workgroup per block walks its tiles.
+ * ============================================================================================================= */
+constexpr uint32_t RLE_THREADS = 512;
+constexpr uint32_t RLE_BYTES_PER_THREAD = 16;
+constexpr uint32_t RLE_TILE = RLE_THREADS * RLE_BYTES_PER_THREAD;
+constexpr uint32_t FN_IDENTITY = 0 | ( 1 << 3 ) | ( 2 << 6 ) | ( 3 << 9 ) | ( 4 << 12 );
+
+__device__ __forceinline__ uint32_t
+fn_apply( uint32_t f, uint32_t k )
+{
+    return ( f >> ( 3 * k ) ) & 7u;
+}
+
+/** (g after f)(k) = g(f(k)) */
+__device__ __forceinline__ uint32_t
+fn_compose( uint32_t f, uint32_t g )
+{
+    uint32_t h = 0;
+#pragma unroll
+    for ( int k = 0; k < 5; ++k ) h |= fn_apply( g, fn_apply( f, k ) ) << ( 3 * k );
+    return h;
+}
+
+__device__ __forceinline__ uint32_t
+rle_step( uint32_t k, bool eq )
+{
+    return eq ? ( k == 4 ? 0u : k + 1 ) : ( k == 4 ? 0u : 1u );
+}
+
+template<bool WRITE>
+__global__ __launch_bounds__( RLE_THREADS ) void
+k_rle( BlockMeta*                   meta,
+       const uint8_t* __restrict__  r_buf,
+       uint8_t* __restrict__        out )
+{
+    __shared__ uint32_t wfn[RLE_THREADS / 64];
+    __shared__ uint64_t wsum[RLE_THREADS / 64];
+    __shared__ uint32_t carryFn;     /* state before the tile (as a constant function value) */
+    __shared__ uint64_t carrySum;
+    const uint32_t b = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t N = mt.n;
+    const uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
+    uint8_t* const dst = WRITE ? out + mt.out_off : nullptr;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    uint32_t stateIn = 0;     /* state before the current tile */
+    uint64_t sumIn = 0;       /* output bytes before the current tile */
+
+    for ( uint32_t tile = 0; tile < N; tile += RLE_TILE ) {
+        const uint32_t i0 = tile + tid * RLE_BYTES_PER_THREAD;
+        uint32_t wv[4] = { 0, 0, 0, 0 };
+        uint32_t prev = 0;
+        uint32_t nb = 0;
+        if ( i0 < N ) {
+            nb = N - i0 < RLE_BYTES_PER_THREAD ? N - i0 : RLE_BYTES_PER_THREAD;
+            const uint4 v = *reinterpret_cast<const uint4*>( R + i0 );   /* R is padded to L_STRIDE */
+            wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+            prev = i0 > 0 ? R[i0 - 1] : 0x100u;
+        }
+        /* eq mask of my bytes */
+        uint32_t eqMask = 0;
+        {
+            uint32_t p = prev;
+            for ( uint32_t q = 0; q < nb; ++q ) {
+                const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
+                eqMask |= ( c == p ? 1u : 0u ) << q;
+                p = c;
+            }
+        }
+        /* my chunk's transition function: 5 tracks */
+        uint32_t fn = FN_IDENTITY;
+        if ( nb > 0 ) {
+            uint32_t t0 = 0, t1 = 1, t2 = 2, t3 = 3, t4 = 4;
+            for ( uint32_t q = 0; q < nb; ++q ) {
+                const bool eq = ( eqMask >> q ) & 1u;
+                t0 = rle_step( t0, eq ); t1 = rle_step( t1, eq ); t2 = rle_step( t2, eq );
+                t3 = rle_step( t3, eq ); t4 = rle_step( t4, eq );
+            }
+            fn = t0 | ( t1 << 3 ) | ( t2 << 6 ) | ( t3 << 9 ) | ( t4 << 12 );
+        }
+        /* exclusive scan of functions: wave level */
+        uint32_t incl = fn;
+        for ( int d = 1; d < 64; d <<= 1 ) {
+            const uint32_t o = __shfl_up( incl, d );
+            if ( (int)lane >= d ) incl = fn_compose( o, incl );
+        }
+        if ( lane == 63 ) wfn[wave] = incl;
+        __syncthreads();
+        uint32_t pre = FN_IDENTITY;   /* composition of all earlier waves */
+        for ( uint32_t w = 0; w < wave; ++w ) pre = fn_compose( pre, wfn[w] );
+        uint32_t exclWave = __shfl_up( incl, 1 );
+        if ( lane == 0 ) exclWave = FN_IDENTITY;
+        const uint32_t before = fn_compose( pre, exclWave );
+        uint32_t k = fn_apply( before, stateIn );
+
+        /* output size of my chunk with the true entry state; remember per-byte class */
+        uint32_t mySize = 0;
+        uint32_t countMask = 0;
+        {
+            uint32_t kk = k;
+            for ( uint32_t q = 0; q < nb; ++q ) {
+                const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
+                if ( kk == 4 ) { mySize += c; countMask |= 1u << q; } else { mySize += 1; }
+                kk = rle_step( kk, ( eqMask >> q ) & 1u );
+            }
+        }
+        /* exclusive sum scan */
+        uint32_t inclS = mySize;
+        for ( int d = 1; d < 64; d <<= 1 ) {
+            const uint32_t o = __shfl_up( inclS, d );
+            if ( (int)lane >= d ) inclS += o;
+        }
+        if ( lane == 63 ) wsum[wave] = inclS;
+        __syncthreads();
+        uint64_t preS = 0, tileTotal = 0;
+        for ( uint32_t w = 0; w < RLE_THREADS / 64; ++w ) {
+            if ( w < wave ) preS += wsum[w];
+            tileTotal += wsum[w];
+        }
+        const uint64_t myOff = sumIn + preS + ( inclS - mySize );
+
+        if constexpr ( WRITE ) {
+            uint64_t o = myOff;
+            uint32_t p = prev;
+            for ( uint32_t q = 0; q < nb; ++q ) {
+                const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
+                if ( ( countMask >> q ) & 1u ) {
+                    for ( uint32_t z = 0; z < c; ++z ) dst[o + z] = (uint8_t)p;
+                    o += c;
+                } else {
+                    dst[o++] = (uint8_t)c;
+                }
+                p = c;
+            }
+        }
+
+        /* carry to the next tile: the last thread's exit state */
+        if ( tid == RLE_THREADS - 1 ) {
+            carryFn = fn_apply( fn_compose( before, fn ), stateIn );
+        }
+        __syncthreads();
+        stateIn = carryFn;
+        sumIn += tileTotal;
+        __syncthreads();
+    }
+    if ( !WRITE && tid == 0 ) {
+        meta[b].decoded_size = sumIn;
+    }
+    (void)carrySum;
+}
+
+/* =============================================================================================================
+ * k_crc: bzip2's MSB-first CRC-32 (poly 0x04C11DB7, bzip2.hpp:59-91) of each block's D output bytes.
+ * Thread t CRCs a 64-byte chunk (zero init); chunks are combined with crc(A|B) = crc(A)*x^(8|B|) + crc(B) in
+ * GF(2)[x]/P.  Tiles are aligned to absolute 64-byte addresses; leading pad bytes are zeros (no effect on a
+ * zero-init CRC), trailing pad is undone with x^(-8*pad).  Init/final XOR are applied at the end.
+ * ============================================================================================================= */
+constexpr uint32_t CRC_THREADS = 256;
+constexpr uint32_t CRC_CHUNK = 64;
+constexpr uint32_t CRC_TILE = CRC_THREADS * CRC_CHUNK;   /* 16 KiB = 64 * 2^8 bytes */
+constexpr uint32_t CRC_POLY = 0x04C11DB7u;
+
+__device__ __forceinline__ uint32_t
+gf_mul( uint32_t a, uint32_t b )
+{
+    /* (a * b) mod P, bit 31 = x^31 */
+    uint32_t r = 0;
+#pragma unroll 8
+    for ( int i = 31; i >= 0; --i ) {
+        r = ( r << 1 ) ^ ( ( r >> 31 ) ? CRC_POLY : 0u );
+        if ( ( a >> i ) & 1u ) r ^= b;
+    }
+    return r;
+}
+
+/** x^(8*nbytes) (or its inverse) by binary decomposition over the precomputed table. */
+__device__ __forceinline__ uint32_t
+gf_pow8( const uint32_t* table, uint64_t nbytes )
+{
+    uint32_t r = 0x00000001u;   /* the polynomial 1 */
+    for ( int k = 0; nbytes != 0 && k < 32; ++k, nbytes >>= 1 ) {
+        if ( nbytes & 1u ) r = gf_mul( r, table[k] );
+    }
+    return r;
+}
+
+__global__ __launch_bounds__( CRC_THREADS ) void
+k_crc( BlockMeta*                  meta,
+       const uint8_t* __restrict__ out,
+       CrcConsts                   cc )
+{
+    __shared__ uint32_t table[256];
+    __shared__ uint32_t wcrc[CRC_THREADS / 64];
+    const uint32_t b = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {
+        uint32_t c = tid << 24;
+        for ( int j = 0; j < 8; ++j ) c = ( c & 0x80000000u ) ? ( c << 1 ) ^ CRC_POLY : ( c << 1 );
+        table[tid] = c;
+    }
+    __syncthreads();
+
+    const uint64_t D = mt.decoded_size;
+    const uint64_t a0 = mt.out_off;           /* absolute byte offsets in `out` */
+    const uint64_t a1 = a0 + D;
+    const uint64_t t0 = a0 & ~(uint64_t)( CRC_TILE - 1 );
+    uint32_t running = 0;
+    uint64_t tEnd = t0;
+    const bool aligned = ( reinterpret_cast<uintptr_t>( out ) & 15u ) == 0;
+    for ( uint64_t t = t0; t < a1; t += CRC_TILE ) {
+        const uint64_t c0 = t + (uint64_t)tid * CRC_CHUNK;
+        uint32_t crc = 0;
+        if ( c0 + CRC_CHUNK > a0 && c0 < a1 ) {
+            if ( aligned && c0 >= a0 && c0 + CRC_CHUNK <= a1 ) {
+                const uint4* src = reinterpret_cast<const uint4*>( out + c0 );
+#pragma unroll
+                for ( int v = 0; v < 4; ++v ) {
+                    const uint4 d = src[v];
+                    const uint32_t ws[4] = { d.x, d.y, d.z, d.w };
+#pragma unroll
+                    for ( int q = 0; q < 4; ++q ) {
+#pragma unroll
+                        for ( int z = 0; z < 4; ++z ) {
+                            const uint32_t byte = ( ws[q] >> ( 8 * z ) ) & 0xFFu;
+                            crc = ( crc << 8 ) ^ table[( crc >> 24 ) ^ byte];
+                        }
+                    }
+                }
+            } else {
+                for ( uint32_t q = 0; q < CRC_CHUNK; ++q ) {
+                    const uint64_t a = c0 + q;
+                    const uint32_t byte = ( a >= a0 && a < a1 ) ? out[a] : 0u;
+                    crc = ( crc << 8 ) ^ table[( crc >> 24 ) ^ byte];
+                }
+            }
+        }
+        /* wave tree: after step d lane i (i % 2d == 0) holds the CRC of chunks [i, i+2d) */
+        for ( int d = 1, k = 6; d < 64; d <<= 1, ++k ) {
+            const uint32_t right = __shfl_down( crc, d );
+            crc = gf_mul( crc, cc.pow8[k] ) ^ right;   /* pow8[k] = x^(8 * 64 * d) since 64*d = 2^k */
+        }
+        if ( lane == 0 ) wcrc[wave] = crc;
+        __syncthreads();
+        if ( tid == 0 ) {
+            uint32_t tileCrc = 0;
+            for ( uint32_t w = 0; w < CRC_THREADS / 64; ++w ) {
+                tileCrc = gf_mul( tileCrc, cc.pow8[12] ) ^ wcrc[w];   /* 4096 bytes per wave */
+            }
+            running = gf_mul( running, cc.pow8[14] ) ^ tileCrc;       /* 16384 bytes per tile */
+        }
+        __syncthreads();
+        tEnd = t + CRC_TILE;
+    }
+    if ( tid == 0 ) {
+        /* undo the trailing zero pad, then add the init contribution 0xFFFFFFFF * x^(8D) and invert */
+        const uint64_t pad = tEnd - a1;
+        uint32_t pure = D == 0 ? 0u : gf_mul( running, gf_pow8( cc.ipow8, pad ) );
+        const uint32_t init = gf_mul( 0xFFFFFFFFu, gf_pow8( cc.pow8, D ) );
+        const uint32_t crc = ~( pure ^ init );
+        meta[b].computed_crc = crc;
+        if ( crc != mt.header_crc ) meta[b].status = ST_CRC;
+    }
+}
+}  // namespace bz2gpu

@@ -1,0 +1,94 @@
+"""Seeded synthetic inputs for the parity tests (encoder = CPython's bz2 module, i.e. libbz2 -- an implementation
+independent of both the reference decoder and this repository)."""
+import bz2
+
+import numpy as np
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def random_bytes(n, seed=1):
+    return rng(seed).integers(0, 256, n, dtype=np.uint8).tobytes()
+
+
+def text_like(n, seed=2):
+    """Zipf-ish words, newline every ~80 chars: compresses ~3-4x like natural text."""
+    r = rng(seed)
+    vocab = [bytes(r.integers(97, 123, int(l), dtype=np.uint8)) for l in r.integers(2, 10, 4096)]
+    idx = np.minimum(r.zipf(1.3, n // 4 + 16) - 1, len(vocab) - 1)
+    out = bytearray()
+    col = 0
+    for i in idx:
+        w = vocab[int(i)]
+        out += w
+        col += len(w) + 1
+        if col > 72:
+            out += b"\n"
+            col = 0
+        else:
+            out += b" "
+        if len(out) >= n:
+            break
+    return bytes(out[:n])
+
+
+def random_text_file(n, seed=3):
+    """The reference's createRandomTextFile: 'A' + rand() % 25, newline every 80 (src/core/DataGenerators.hpp:17-26)."""
+    r = rng(seed)
+    a = (r.integers(0, 25, n, dtype=np.uint8) + 65).astype(np.uint8)
+    a[79::80] = 10
+    return a.tobytes()
+
+
+def runs(n, seed=4, maxrun=700):
+    """Byte runs of random length (exercises RLE1 counts 0..255 and RUNA/RUNB)."""
+    r = rng(seed)
+    out = bytearray()
+    while len(out) < n:
+        out += bytes([int(r.integers(0, 256))]) * int(r.integers(1, maxrun))
+    return bytes(out[:n])
+
+
+def ab_stripes(n, stripe):
+    """AB stripes as in src/tests/testPythonWrappers.py:171-245."""
+    unit = b"A" * stripe + b"B" * stripe
+    return (unit * (n // len(unit) + 1))[:n]
+
+
+def compress(data, level=9):
+    return bz2.compress(data, level)
+
+
+def corpus_small():
+    """name -> (raw, level) : fast cases for both CPU and GPU suites."""
+    cases = {
+        "rand-1": (random_bytes(1, 11), 9),
+        "rand-300k-l9": (random_bytes(300_000, 12), 9),
+        "rand-250k-l1": (random_bytes(250_000, 13), 1),      # 3 blocks at level 1
+        "text-1.2M-l9": (text_like(1_200_000, 14), 9),        # 2 blocks
+        "text-400k-l1": (text_like(400_000, 15), 1),          # several 100k blocks
+        "reftext-2MiB-l9": (random_text_file(2 * 1024 * 1024, 16), 9),  # the reference test's 3-block file
+        "runs-500k-l9": (runs(500_000, 17), 9),
+        "runs-short-l5": (runs(200_000, 18, 9), 5),
+        "zeros-3M-l9": (bytes(3_000_000), 9),
+        "ff-2M-l9": (b"\xff" * 2_000_000, 9),                 # RLE1 count byte == run byte (0xFF)
+        "fb-259k": (b"\xfb" * 259_000, 9),
+        "A-512Ki+2-l1": (b"A" * (512 * 1024 + 2), 1),         # testPythonWrappers.py:476-500 regression sizes
+        "ab-1": (ab_stripes(100_000, 1), 9),
+        "ab-2": (ab_stripes(100_000, 2), 9),
+        "ab-8": (ab_stripes(100_000, 8), 9),
+        "ab-123": (ab_stripes(100_000, 123), 9),
+        "ab-257": (ab_stripes(200_000, 257), 9),
+        "ab-2048": (ab_stripes(200_000, 2048), 3),
+        "4-4-4-4": (b"\x04" * 8 * 1000, 9),
+        "two-symbols": (b"ab" * 5000, 9),
+        "one-symbol-3": (b"zzz", 9),
+        "all-bytes": (bytes(range(256)) * 40, 9),
+    }
+    return cases
+
+
+def multistream(parts, level=9):
+    return b"".join(bz2.compress(p, level) for p in parts)

@@ -1,0 +1,104 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on identical inputs. Bit-exact.
+
+Run on the GPU box: python -m pytest tests -m gpu -x -q
+"""
+import hashlib
+
+import pytest
+
+from conftest import fixture_names, read_fixture
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dec(native):
+    d = native.Decoder(flags=native.Decoder.KEEP_STAGES)
+    yield d
+    d.close()
+
+
+def check_blocks(native, oracle, dec, enc, expect_raw=None, check_stages=True):
+    offs = oracle.find_magic(enc)
+    assert native.find_magic(enc) == offs
+    dec.set_input(enc)
+    results, total = dec.decode_batch(offs)
+    out = dec.copy_output(0, total)
+    pos = 0
+    for i, (o, r) in enumerate(zip(offs, results)):
+        if check_stages:
+            od, payload, lcol, rle = oracle.decode_block(enc, o, want_stages=True)
+        else:
+            od, payload = oracle.decode_block(enc, o)
+        for key in ("encoded_offset_bits", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc",
+                    "bwt_length", "orig_ptr", "n_symbols", "is_eos", "is_eof", "status"):
+            assert r[key] == od[key], f"block {i} @bit {o}: {key}: gpu {r[key]} != oracle {od[key]}"
+        if od["status"] == 0:
+            if check_stages:
+                assert dec.debug_stage(i, 0) == lcol, f"block {i}: L column differs"
+                assert dec.debug_stage(i, 2) == rle, f"block {i}: inverse-BWT output differs"
+            assert r["data_offset"] == pos
+            got = out[pos:pos + r["decoded_size"]]
+            assert hashlib.sha256(got).digest() == hashlib.sha256(payload).digest(), f"block {i}: payload differs"
+            pos += r["decoded_size"]
+    assert pos == total
+    if expect_raw is not None:
+        assert out == expect_raw
+    return results
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_reference_fixtures(native, oracle, dec, name):
+    enc, raw = read_fixture(name)
+    check_blocks(native, oracle, dec, enc, raw)
+
+
+@pytest.mark.parametrize("name", sorted(datagen.corpus_small()))
+def test_generated(native, oracle, dec, name):
+    raw, level = datagen.corpus_small()[name]
+    enc = datagen.compress(raw, level)
+    check_blocks(native, oracle, dec, enc, raw)
+
+
+def test_multistream(native, oracle, dec):
+    parts = [datagen.text_like(250_000, 31), datagen.random_bytes(150_000, 32), b"", b"x", datagen.runs(99_999, 33)]
+    enc = datagen.multistream(parts, 1)
+    check_blocks(native, oracle, dec, enc, b"".join(parts))
+
+
+def test_eos_offset_and_errors(native, oracle, dec):
+    enc, raw = read_fixture("base64-32KiB")
+    eos = oracle.find_magic(enc, oracle.MAGIC_EOS)
+    assert len(eos) == 1
+    dec.set_input(enc)
+    # EOS offset, a non-magic offset, and an offset past the end
+    offs = [eos[0], 33, len(enc) * 8 + 5, 32]
+    results, total = dec.decode_batch(offs)
+    for o, r in zip(offs, results):
+        od, payload = oracle.decode_block(enc, o)
+        for key in ("encoded_size_bits", "decoded_size", "header_crc", "is_eos", "is_eof", "status"):
+            assert r[key] == od[key], (o, key, r[key], od[key])
+    assert results[0]["is_eos"] == 1 and results[0]["is_eof"] == 1
+    assert results[1]["status"] == 2 and results[2]["status"] == 1
+    assert dec.copy_output(results[3]["data_offset"], results[3]["decoded_size"]) == raw
+
+
+def test_corrupt_crc_and_truncation(native, oracle, dec):
+    raw = datagen.text_like(200_000, 41)
+    enc = bytearray(datagen.compress(raw, 9))
+    # flip a bit in the middle of the Huffman data: CRC mismatch or a structural error -- must agree with the oracle
+    for flip in (len(enc) // 2, len(enc) // 3, 40, 60, 100, 2000):
+        bad = bytearray(enc)
+        bad[flip] ^= 0x10
+        bad = bytes(bad)
+        dec.set_input(bad)
+        results, total = dec.decode_batch([32])
+        od, _ = oracle.decode_block(bad, 32)
+        assert results[0]["status"] == od["status"], (flip, results[0], od)
+    for cut in (len(enc) - 11, len(enc) // 2, 100, 20, 9):
+        bad = bytes(enc[:cut])
+        dec.set_input(bad)
+        results, total = dec.decode_batch([32])
+        od, _ = oracle.decode_block(bad, 32)
+        assert results[0]["status"] == od["status"], (cut, results[0], od)
