@@ -341,6 +341,7 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     hipLaunchKernelGGL( k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
     hipLaunchKernelGGL( k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
                         c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+    hipLaunchKernelGGL( k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
     HIP_TRY( c, hipEventRecord( c->ev[3], c->stream ) );
     hipLaunchKernelGGL( k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
     HIP_TRY( c, hipGetLastError() );

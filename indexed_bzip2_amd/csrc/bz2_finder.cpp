@@ -14,12 +14,13 @@
 #include <vector>
 
 #include "../../include/mi355x_bz2.h"
+#include "bz2_host.hpp"
 
-namespace
+namespace mi355x
 {
 /** All matches whose FIRST byte B lies in [begin, end); reads up to byte B+6. Sorted ascending. */
 void
-scanRange( const uint8_t* bytes, uint64_t size, uint64_t magic48, uint64_t begin, uint64_t end,
+scanMagicRange( const uint8_t* bytes, uint64_t size, uint64_t magic48, uint64_t begin, uint64_t end,
            std::vector<uint64_t>& found )
 {
     constexpr uint64_t SUB = 1u << 20;
@@ -60,7 +61,9 @@ scanRange( const uint8_t* bytes, uint64_t size, uint64_t magic48, uint64_t begin
         std::sort( found.begin() + (std::ptrdiff_t)firstNew, found.end() );
     }
 }
-}  // namespace
+}  // namespace mi355x
+
+using mi355x::scanMagicRange;
 
 extern "C" uint64_t
 mi355x_bz2_find_magic( const uint8_t* bytes, uint64_t size, uint64_t magic48,
@@ -73,14 +76,14 @@ mi355x_bz2_find_magic( const uint8_t* bytes, uint64_t size, uint64_t magic48,
     T = (unsigned)std::max<uint64_t>( 1, std::min<uint64_t>( T, ( size + minChunk - 1 ) / minChunk ) );
     std::vector<std::vector<uint64_t> > results( T );
     if ( T == 1 ) {
-        scanRange( bytes, size, magic48, 0, size, results[0] );
+        scanMagicRange( bytes, size, magic48, 0, size, results[0] );
     } else {
         std::vector<std::thread> pool;
         const uint64_t chunk = ( size + T - 1 ) / T;
         for ( unsigned t = 0; t < T; ++t ) {
             const uint64_t b = std::min<uint64_t>( size, (uint64_t)t * chunk );
             const uint64_t e = std::min<uint64_t>( size, b + chunk );
-            pool.emplace_back( [&, t, b, e] () { scanRange( bytes, size, magic48, b, e, results[t] ); } );
+            pool.emplace_back( [&, t, b, e] () { scanMagicRange( bytes, size, magic48, b, e, results[t] ); } );
         }
         for ( auto& th : pool ) th.join();
     }

@@ -61,7 +61,7 @@ struct BlockMeta
     uint32_t seg_stride;
     uint32_t nseg;
     uint32_t walk_ok;    /* 1 if stages >= walk should run */
-    uint32_t pad;
+    uint32_t cycle_len;  /* length of the permutation cycle through origPtr (== N unless the block is periodic) */
 };
 
 struct CrcConsts
@@ -539,7 +539,7 @@ finish:
         mt.seg_stride = stride;
         mt.nseg = k0 + ( ( N > 0 && origPtr % stride != 0 ) ? 1u : 0u );
         mt.walk_ok = ( status == ST_OK && !isEos && N > 0 ) ? 1u : 0u;
-        mt.pad = 0;
+        mt.cycle_len = 0;
         meta[b] = mt;
     }
 }
@@ -696,8 +696,12 @@ k_walk( const BlockMeta* __restrict__ meta,
 
 /* =============================================================================================================
  * k_link: order the segments along the cycle starting at origPtr and prefix-sum their lengths.
- * A valid block is one N-cycle, so the chain visits every segment once and the lengths sum to N; anything else
- * (corrupt data that still Huffman-decoded) cannot match its CRC in the reference either -> ST_CRC.
+ * LF is always a permutation, so the chain returns to its first segment after c = (cycle length) steps.  For
+ * ordinary data c == N.  For periodic data (e.g. "abab...": the sorted rotations repeat) the permutation splits
+ * into N/c cycles and the reference's N-step walk (bzip2.hpp:872-879) simply goes round the origPtr cycle N/c
+ * times -- the output is the first period repeated.  Segments off the cycle keep INVALID_OFF and are not emitted;
+ * k_replicate copies the first period into the rest of the stream.  Corrupt data takes the same path and is
+ * caught by the CRC, exactly as in the reference.
  * ============================================================================================================= */
 __global__ __launch_bounds__( 256 ) void
 k_link( BlockMeta*                   meta,
@@ -731,10 +735,26 @@ k_link( BlockMeta*                   meta,
             ++visited;
             if ( cur == 0xFFFFu || visited > nseg || off > N ) { ok = false; break; }
         } while ( cur != first );
-        if ( !ok || off != N ) {
+        meta[b].cycle_len = off;
+        if ( !ok || off == 0 ) {   /* unreachable for a permutation: guards against table corruption */
             meta[b].status = ST_CRC;
             meta[b].walk_ok = 0;
         }
+    }
+}
+
+/** Periodic blocks only: R[N-1-k] = R[N-1-(k mod c)] for k >= c (see k_link). */
+__global__ __launch_bounds__( 256 ) void
+k_replicate( const BlockMeta* __restrict__ meta,
+             uint8_t*                      r_buf )
+{
+    const uint32_t b = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok || mt.cycle_len >= mt.n || mt.cycle_len == 0 ) return;
+    const uint32_t N = mt.n, c = mt.cycle_len;
+    uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
+    for ( uint32_t k = c + threadIdx.x; k < N; k += 256 ) {
+        R[N - 1 - k] = R[N - 1 - ( k % c )];
     }
 }
 

@@ -1,0 +1,1084 @@
+/**
+ * bz2_reader.cpp -- reader + GPU block fetcher behind C ABI section 3 of include/mi355x_bz2.h.
+ *
+ *   GpuBlockFetcher  <- rapidgzip::BlockFetcher::get / prefetchNewBlocks    src/core/BlockFetcher.hpp:244-317, 446-559
+ *                       + BZ2BlockFetcher::{readBlockHeader, decodeBlock}   src/indexed_bzip2/BZ2BlockFetcher.hpp:64-138
+ *   ParallelReader   <- indexed_bzip2::ParallelBZ2Reader                    src/indexed_bzip2/ParallelBZ2Reader.hpp:39-498
+ *
+ * What is kept from the reference: the block finder running ahead on its own thread, the LRU cache + prefetch cache +
+ * failed-prefetch cache, the adaptive prefetch strategy, "prefetch failures are silent, on-demand failures surface",
+ * the block map and the whole read/seek state machine.
+ * What is different by design (GPU backend): the thread pool of per-block tasks is replaced by ONE submission thread
+ * that pushes BATCHES of blocks through mi355x_bz2_decode_batch; prefetches are issued in batches of >= P/2 blocks so
+ * that every launch has enough independent blocks to fill the GPU.
+ */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <future>
+#include <iostream>
+#include <memory>
+#include <queue>
+#include <string>
+
+#include "../../include/mi355x_bz2.h"
+#include "bz2_host.hpp"
+
+namespace mi355x
+{
+struct Bz2Exception : public std::runtime_error
+{
+    Bz2Exception( int statusCode, const std::string& message ) :
+        std::runtime_error( message ),
+        status( statusCode )
+    {}
+
+    int status;
+};
+
+[[noreturn]] static void
+fail( int status, const std::string& detail = {} )
+{
+    std::string message = mi355x_bz2_status_string( status );
+    if ( !detail.empty() ) {
+        message += ": " + detail;
+    }
+    throw Bz2Exception( status, message );
+}
+
+/* ------------------------------------------------------------------------------------------------ compressed source */
+class Source
+{
+public:
+    static std::shared_ptr<Source>
+    fromFd( int fd, bool closeFd )
+    {
+        struct stat st{};
+        if ( fstat( fd, &st ) != 0 || !S_ISREG( st.st_mode ) ) {
+            if ( closeFd ) ::close( fd );
+            /* ParallelBZ2Reader.hpp:66-68 */
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "Parallel BZ2 Reader will not work on non-seekable input like stdin (yet)!" );
+        }
+        auto s = std::shared_ptr<Source>( new Source() );
+        s->m_size = (uint64_t)st.st_size;
+        if ( s->m_size > 0 ) {
+            void* p = mmap( nullptr, s->m_size, PROT_READ, MAP_PRIVATE, fd, 0 );
+            if ( p == MAP_FAILED ) {
+                const int e = errno;
+                if ( closeFd ) ::close( fd );
+                fail( MI355X_BZ2_ERR_IO, std::string( "mmap: " ) + strerror( e ) );
+            }
+            s->m_map = p;
+            s->m_bytes = static_cast<const uint8_t*>( p );
+            (void)madvise( p, s->m_size, MADV_SEQUENTIAL );
+        }
+        if ( closeFd ) ::close( fd );
+        return s;
+    }
+
+    static std::shared_ptr<Source>
+    fromPath( const char* path )
+    {
+        const int fd = ::open( path, O_RDONLY | O_CLOEXEC );
+        if ( fd < 0 ) {
+            fail( MI355X_BZ2_ERR_IO, std::string( "open(" ) + path + "): " + strerror( errno ) );
+        }
+        return fromFd( fd, true );
+    }
+
+    static std::shared_ptr<Source>
+    fromMemory( const uint8_t* bytes, uint64_t size )
+    {
+        auto s = std::shared_ptr<Source>( new Source() );
+        s->m_copy.assign( bytes, bytes + size );
+        s->m_bytes = s->m_copy.data();
+        s->m_size = size;
+        return s;
+    }
+
+    ~Source()
+    {
+        if ( m_map != nullptr ) {
+            munmap( m_map, m_size );
+        }
+    }
+
+    [[nodiscard]] const uint8_t* bytes() const { return m_bytes; }
+    [[nodiscard]] uint64_t size() const { return m_size; }
+    [[nodiscard]] uint64_t sizeInBits() const { return m_size * 8; }
+
+private:
+    Source() = default;
+    const uint8_t* m_bytes{ nullptr };
+    uint64_t m_size{ 0 };
+    void* m_map{ nullptr };
+    std::vector<uint8_t> m_copy;
+};
+
+/** MSB-first read of up to 32 bits from a byte array; sets eof if it crosses the end (BitReader.hpp:190-206). */
+static uint32_t
+readBits( const Source& src, uint64_t& pos, unsigned n, bool& eof )
+{
+    if ( pos + n > src.sizeInBits() ) {
+        eof = true;
+        return 0;
+    }
+    uint64_t v = 0;
+    const uint64_t byte = pos >> 3;
+    for ( int i = 0; i < 8; ++i ) {
+        v = ( v << 8 ) | ( byte + i < src.size() ? src.bytes()[byte + i] : 0 );
+    }
+    v <<= ( pos & 7 );
+    pos += n;
+    return n == 0 ? 0 : (uint32_t)( v >> ( 64 - n ) );
+}
+
+/* ------------------------------------------------------------------------------------------------ block records */
+/** indexed_bzip2::BlockHeaderData / BlockData, BZ2BlockFetcher.hpp:18-34 */
+struct BlockHeaderData
+{
+    size_t encodedOffsetInBits{ std::numeric_limits<size_t>::max() };
+    size_t encodedSizeInBits{ 0 };
+    uint32_t expectedCRC{ 0 };
+    bool isEndOfStreamBlock{ false };
+    bool isEndOfFile{ false };
+};
+
+struct BlockData : public BlockHeaderData
+{
+    std::shared_ptr<const std::vector<uint8_t> > buffer;   /* host copy of the whole batch output */
+    size_t dataOffset{ 0 };
+    size_t dataSize{ 0 };
+    uint32_t calculatedCRC{ 0xFFFFFFFFu };
+    int status{ MI355X_BZ2_OK };
+
+    [[nodiscard]] const uint8_t* data() const { return buffer ? buffer->data() + dataOffset : nullptr; }
+};
+
+using BlockDataPtr = std::shared_ptr<BlockData>;
+
+/* ------------------------------------------------------------------------------------------------ GPU block fetcher */
+class GpuBlockFetcher
+{
+public:
+    GpuBlockFetcher( std::shared_ptr<Source> source, std::shared_ptr<BlockFinder> finder,
+                     size_t parallelization, int device ) :
+        m_source( std::move( source ) ),
+        m_blockFinder( std::move( finder ) ),
+        m_parallelization( std::max<size_t>( 1, parallelization ) ),
+        m_cache( std::max<size_t>( 16, m_parallelization ) ),              /* BlockFetcher.hpp:180 */
+        m_prefetchCache( 2 * m_parallelization ),                          /* BlockFetcher.hpp:181 */
+        m_failedPrefetchCache( 2 * m_parallelization )                     /* BlockFetcher.hpp:182 */
+    {
+        /* BZ2BlockFetcher ctor reads the stream header once: BZ2BlockFetcher.hpp:56 */
+        if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), 0 ) == 0 ) {
+            fail( MI355X_BZ2_ERR_STREAM_HEADER );
+        }
+        mi355x_bz2_config config{};
+        config.device = device;
+        config.max_batch_blocks = (uint32_t)std::min<size_t>( m_parallelization, 4096 );
+        const int rc = mi355x_bz2_create( &config, &m_ctx );
+        if ( rc != MI355X_BZ2_OK ) {
+            fail( rc );
+        }
+        const int rc2 = mi355x_bz2_set_input_host( m_ctx, m_source->bytes(), m_source->size() );
+        if ( rc2 != MI355X_BZ2_OK ) {
+            const std::string detail = mi355x_bz2_last_error( m_ctx );
+            mi355x_bz2_destroy( m_ctx );
+            m_ctx = nullptr;
+            fail( rc2, detail );
+        }
+        m_worker = std::thread( [this] () { workerMain(); } );
+    }
+
+    ~GpuBlockFetcher()
+    {
+        {
+            const std::scoped_lock lock( m_queueMutex );
+            m_stop = true;
+            m_queueChanged.notify_all();
+        }
+        if ( m_worker.joinable() ) {
+            m_worker.join();
+        }
+        m_prefetching.clear();
+        if ( m_ctx != nullptr ) {
+            mi355x_bz2_destroy( m_ctx );
+        }
+    }
+
+    /** BZ2BlockFetcher::readBlockHeader, BZ2BlockFetcher.hpp:64-82, for the EOS / next-stream probe on the caller
+     * thread.  Host-side parse of magic, CRC, randomised bit and origPtr (bzip2.hpp:479-519); the tree section of a
+     * data block is validated when that block is decoded on the GPU. */
+    [[nodiscard]] BlockHeaderData
+    readBlockHeader( size_t blockOffset ) const
+    {
+        BlockHeaderData result;
+        result.encodedOffsetInBits = blockOffset;
+        uint64_t pos = blockOffset;
+        bool eof = blockOffset > m_source->sizeInBits();
+        const uint64_t hi = readBits( *m_source, pos, 24, eof );
+        const uint64_t lo = readBits( *m_source, pos, 24, eof );
+        result.expectedCRC = readBits( *m_source, pos, 32, eof );
+        if ( eof ) fail( MI355X_BZ2_ERR_EOF );
+        const uint64_t magic = ( hi << 24 ) | lo;
+        if ( magic == MI355X_BZ2_MAGIC_EOS ) {
+            result.isEndOfStreamBlock = true;
+            if ( ( pos & 7 ) != 0 ) {
+                readBits( *m_source, pos, 8 - (unsigned)( pos & 7 ), eof );
+                if ( eof ) fail( MI355X_BZ2_ERR_EOF );
+            }
+            result.encodedSizeInBits = pos - blockOffset;
+            result.isEndOfFile = pos >= m_source->sizeInBits();
+            return result;
+        }
+        if ( magic != MI355X_BZ2_MAGIC_BLOCK ) {
+            char buffer[96];
+            std::snprintf( buffer, sizeof( buffer ), "0x%llx at bit offset %llu", (unsigned long long)magic,
+                           (unsigned long long)blockOffset );
+            fail( MI355X_BZ2_ERR_BAD_MAGIC, buffer );
+        }
+        const uint32_t randomized = readBits( *m_source, pos, 1, eof );
+        if ( eof ) fail( MI355X_BZ2_ERR_EOF );
+        if ( randomized != 0 ) fail( MI355X_BZ2_ERR_RANDOMIZED );
+        const uint32_t origPtr = readBits( *m_source, pos, 24, eof );
+        if ( eof ) fail( MI355X_BZ2_ERR_EOF );
+        if ( origPtr > 900000 ) fail( MI355X_BZ2_ERR_ORIGPTR_RANGE );
+        return result;
+    }
+
+    /** BlockFetcher::get, BlockFetcher.hpp:244-317 */
+    [[nodiscard]] BlockDataPtr
+    get( size_t blockOffset, std::optional<size_t> dataBlockIndex = std::nullopt )
+    {
+        const auto tStart = std::chrono::steady_clock::now();
+        ++m_stats.gets;
+
+        /* getFromCaches, BlockFetcher.hpp:369-391 */
+        std::shared_future<BlockDataPtr> queued;
+        std::optional<BlockDataPtr> cached;
+        if ( const auto match = m_prefetching.find( blockOffset ); match != m_prefetching.end() ) {
+            queued = match->second;
+            m_prefetching.erase( match );
+            ++m_stats.prefetch_hits;
+        } else {
+            cached = m_cache.get( blockOffset );
+            if ( cached ) {
+                ++m_stats.cache_hits;
+            } else {
+                cached = m_prefetchCache.get( blockOffset );
+                if ( cached ) {
+                    ++m_stats.prefetch_hits;
+                    m_prefetchCache.evict( blockOffset );
+                    insertIntoCache( blockOffset, *cached );
+                }
+            }
+        }
+
+        const auto validDataBlockIndex = dataBlockIndex ? *dataBlockIndex : m_blockFinder->find( blockOffset );
+
+        std::vector<uint64_t> batch;
+        const bool onDemand = !cached.has_value() && !queued.valid();
+        if ( onDemand ) {
+            ++m_stats.on_demand_fetches;
+            batch.push_back( blockOffset );
+        }
+
+        m_fetchingStrategy.fetch( validDataBlockIndex );
+        collectPrefetches( batch, onDemand, blockOffset );
+
+        if ( !batch.empty() ) {
+            auto futures = submitBatch( batch );
+            size_t first = 0;
+            if ( onDemand ) {
+                queued = futures[0];
+                first = 1;
+            }
+            for ( size_t i = first; i < batch.size(); ++i ) {
+                m_prefetching.emplace( batch[i], futures[i] );
+                ++m_stats.prefetches_submitted;
+            }
+        }
+
+        if ( cached.has_value() ) {
+            return *cached;
+        }
+
+        const auto tWait = std::chrono::steady_clock::now();
+        auto result = queued.get();
+        m_stats.wait_seconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - tWait ).count();
+        if ( !result ) {
+            fail( MI355X_BZ2_ERR_DEVICE, m_workerError );
+        }
+        if ( result->status != MI355X_BZ2_OK ) {
+            /* on-demand failures surface to the caller (BlockFetcher.hpp:305) */
+            fail( result->status, "block at bit offset " + std::to_string( blockOffset ) );
+        }
+        insertIntoCache( blockOffset, result );
+        (void)tStart;
+        return result;
+    }
+
+    [[nodiscard]] mi355x_bz2_reader_stats
+    statistics() const
+    {
+        auto result = m_stats;
+        {
+            const std::scoped_lock lock( m_queueMutex );
+            result.batches = m_batches;
+            result.blocks_decoded = m_blocksDecoded;
+            result.decode_seconds = m_decodeSeconds;
+        }
+        return result;
+    }
+
+private:
+    struct Request
+    {
+        std::vector<uint64_t> offsets;
+        std::vector<std::promise<BlockDataPtr> > promises;
+    };
+
+    void
+    insertIntoCache( size_t blockOffset, BlockDataPtr blockData )
+    {
+        if ( m_fetchingStrategy.isSequential() ) {
+            m_cache.clear();   /* BlockFetcher.hpp:343-346 */
+        }
+        m_cache.insert( blockOffset, std::move( blockData ) );
+    }
+
+    [[nodiscard]] bool
+    isInCacheOrQueue( size_t blockOffset ) const
+    {
+        return ( m_prefetching.find( blockOffset ) != m_prefetching.end() )
+               || m_cache.test( blockOffset ) || m_prefetchCache.test( blockOffset );
+    }
+
+    /** processReadyPrefetches, BlockFetcher.hpp:414-438 */
+    void
+    processReadyPrefetches()
+    {
+        using namespace std::chrono_literals;
+        for ( auto it = m_prefetching.begin(); it != m_prefetching.end(); ) {
+            if ( it->second.wait_for( 0s ) == std::future_status::ready ) {
+                const auto result = it->second.get();
+                if ( result && ( result->status == MI355X_BZ2_OK ) ) {
+                    m_prefetchCache.insert( it->first, result );
+                } else {
+                    /* Prefetching failed: ignore result and error; it is retried (and reported) on demand. */
+                    m_failedPrefetchCache.insert( it->first, true );
+                    ++m_stats.failed_prefetches;
+                }
+                it = m_prefetching.erase( it );
+            } else {
+                ++it;
+            }
+        }
+    }
+
+    /** prefetchNewBlocks, BlockFetcher.hpp:446-559, batch-oriented. */
+    void
+    collectPrefetches( std::vector<uint64_t>& batch, bool onDemand, size_t requestedOffset )
+    {
+        processReadyPrefetches();
+        const auto inFlight = m_prefetching.size() + ( onDemand ? 1 : 0 );
+        if ( inFlight >= m_parallelization ) return;   /* threadPoolSaturated, BlockFetcher.hpp:453-460 */
+        const size_t room = m_parallelization - inFlight;
+
+        const auto indexes = m_fetchingStrategy.prefetch( m_prefetchCache.capacity() );
+        std::vector<uint64_t> candidates;
+        for ( const auto index : indexes ) {
+            if ( candidates.size() >= room ) break;
+            if ( m_blockFinder->finalized() && ( index >= m_blockFinder->size() ) ) continue;
+            const auto [offset, code] = m_blockFinder->get( index, /* timeout */ 0 );
+            if ( !offset ) continue;
+            if ( *offset == requestedOffset || isInCacheOrQueue( *offset ) || m_failedPrefetchCache.test( *offset ) ) {
+                m_prefetchCache.touch( *offset );
+                m_cache.touch( *offset );
+                continue;
+            }
+            /* Avoid cache pollution: stop when results that are still wanted would be evicted (BlockFetcher.hpp:527-535) */
+            if ( m_prefetching.size() + candidates.size() + 1 > m_prefetchCache.capacity() ) break;
+            candidates.push_back( *offset );
+        }
+        if ( candidates.empty() ) return;
+        /* GPU batching rule: piggy-back on an on-demand launch, otherwise wait until at least P/2 blocks can go in one
+         * launch (or nothing is in flight at all). */
+        const size_t batchMin = std::max<size_t>( 1, m_parallelization / 2 );
+        if ( onDemand || ( candidates.size() >= batchMin ) || m_prefetching.empty() ) {
+            batch.insert( batch.end(), candidates.begin(), candidates.end() );
+        }
+    }
+
+    [[nodiscard]] std::vector<std::shared_future<BlockDataPtr> >
+    submitBatch( const std::vector<uint64_t>& offsets )
+    {
+        auto request = std::make_unique<Request>();
+        request->offsets = offsets;
+        request->promises.resize( offsets.size() );
+        std::vector<std::shared_future<BlockDataPtr> > futures;
+        futures.reserve( offsets.size() );
+        for ( auto& promise : request->promises ) {
+            futures.emplace_back( promise.get_future().share() );
+        }
+        {
+            const std::scoped_lock lock( m_queueMutex );
+            m_queue.push( std::move( request ) );
+            m_queueChanged.notify_all();
+        }
+        return futures;
+    }
+
+    /** The single GPU submission thread: replaces ThreadPool workers calling decodeBlock (BlockFetcher.hpp:620-642). */
+    void
+    workerMain()
+    {
+        while ( true ) {
+            std::unique_ptr<Request> request;
+            {
+                std::unique_lock lock( m_queueMutex );
+                m_queueChanged.wait( lock, [this] { return m_stop || !m_queue.empty(); } );
+                if ( m_queue.empty() ) {
+                    return;   /* m_stop */
+                }
+                request = std::move( m_queue.front() );
+                m_queue.pop();
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto n = (uint32_t)request->offsets.size();
+            std::vector<mi355x_bz2_block_result> results( n );
+            uint64_t total = 0;
+            int rc = mi355x_bz2_decode_batch( m_ctx, request->offsets.data(), n, results.data(), &total );
+            std::shared_ptr<std::vector<uint8_t> > buffer;
+            if ( rc == MI355X_BZ2_OK ) {
+                buffer = std::make_shared<std::vector<uint8_t> >( total );
+                if ( total > 0 ) {
+                    rc = mi355x_bz2_copy_output( m_ctx, 0, total, buffer->data() );
+                }
+            }
+            if ( rc != MI355X_BZ2_OK ) {
+                m_workerError = mi355x_bz2_last_error( m_ctx );
+                for ( auto& promise : request->promises ) {
+                    promise.set_value( nullptr );
+                }
+                continue;
+            }
+            for ( uint32_t i = 0; i < n; ++i ) {
+                const auto& r = results[i];
+                auto block = std::make_shared<BlockData>();
+                block->encodedOffsetInBits = request->offsets[i];
+                block->encodedSizeInBits = r.encoded_size_bits;
+                block->expectedCRC = r.header_crc;
+                block->calculatedCRC = r.computed_crc;
+                block->isEndOfStreamBlock = r.is_eos != 0;
+                block->isEndOfFile = r.is_eof != 0;
+                block->status = r.status;
+                if ( r.status == MI355X_BZ2_OK ) {
+                    block->buffer = buffer;
+                    block->dataOffset = r.data_offset;
+                    block->dataSize = r.decoded_size;
+                }
+                request->promises[i].set_value( std::move( block ) );
+            }
+            const std::scoped_lock lock( m_queueMutex );
+            ++m_batches;
+            m_blocksDecoded += n;
+            m_decodeSeconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+        }
+    }
+
+private:
+    const std::shared_ptr<Source> m_source;
+    const std::shared_ptr<BlockFinder> m_blockFinder;
+    const size_t m_parallelization;
+
+    FetchNextAdaptive m_fetchingStrategy;
+    LruCache<size_t, BlockDataPtr> m_cache;
+    LruCache<size_t, BlockDataPtr> m_prefetchCache;
+    LruCache<size_t, bool> m_failedPrefetchCache;
+    std::map<size_t, std::shared_future<BlockDataPtr> > m_prefetching;
+
+    mi355x_bz2_ctx* m_ctx{ nullptr };
+    std::thread m_worker;
+    mutable std::mutex m_queueMutex;
+    std::condition_variable m_queueChanged;
+    std::queue<std::unique_ptr<Request> > m_queue;
+    bool m_stop{ false };
+    std::string m_workerError;
+    uint64_t m_batches{ 0 };
+    uint64_t m_blocksDecoded{ 0 };
+    double m_decodeSeconds{ 0 };
+
+    mi355x_bz2_reader_stats m_stats{};
+};
+
+/* ------------------------------------------------------------------------------------------------ the reader */
+class ParallelReader
+{
+public:
+    ParallelReader( std::shared_ptr<Source> source, size_t parallelization, int device ) :
+        m_source( std::move( source ) ),
+        m_parallelization( parallelization == 0 ? DEFAULT_PARALLELIZATION : parallelization ),
+        m_device( device )
+    {}
+
+    static constexpr size_t DEFAULT_PARALLELIZATION = 64;
+
+    void
+    close()   /* ParallelBZ2Reader.hpp:104-111 */
+    {
+        m_blockFetcher.reset();
+        m_blockFinder.reset();
+        m_source.reset();
+    }
+
+    [[nodiscard]] bool closed() const { return !m_source; }
+    [[nodiscard]] bool eof() const { return m_atEndOfFile; }
+
+    [[nodiscard]] size_t
+    tell() const   /* :129-142 */
+    {
+        if ( m_atEndOfFile ) {
+            const auto fileSize = size();
+            if ( !fileSize ) {
+                fail( MI355X_BZ2_ERR_LOGIC, "When the file end has been reached, the block map should have been "
+                                            "finalized and the file size should be available!" );
+            }
+            return *fileSize;
+        }
+        return m_currentPosition;
+    }
+
+    [[nodiscard]] std::optional<size_t>
+    size() const   /* :144-151 */
+    {
+        if ( !m_blockMap.finalized() ) {
+            return std::nullopt;
+        }
+        return m_blockMap.back().second;
+    }
+
+    using WriteFunctor = std::function<void( const void*, uint64_t )>;
+
+    /** ParallelBZ2Reader::read, ParallelBZ2Reader.hpp:167-269 */
+    size_t
+    read( const WriteFunctor& writeFunctor, size_t nBytesToRead = std::numeric_limits<size_t>::max() )
+    {
+        if ( closed() ) {
+            fail( MI355X_BZ2_ERR_CLOSED, "You may not call read on closed ParallelBZ2Reader!" );
+        }
+        if ( eof() || ( nBytesToRead == 0 ) ) {
+            return 0;
+        }
+        size_t nBytesDecoded = 0;
+        while ( ( nBytesDecoded < nBytesToRead ) && !eof() ) {
+            BlockDataPtr blockData;
+            auto blockInfo = m_blockMap.findDataOffset( m_currentPosition );
+            if ( !blockInfo.contains( m_currentPosition ) ) {
+                /* Fetch new block for the first time and add information to block map. */
+                const auto dataBlockIndex = m_blockMap.dataBlockCount();
+                const auto encodedOffsetInBits = blockFinder().get( dataBlockIndex ).first;
+                if ( !encodedOffsetInBits ) {
+                    m_blockMap.finalize();
+                    m_atEndOfFile = true;
+                    break;
+                }
+                blockData = blockFetcher().get( *encodedOffsetInBits, dataBlockIndex );
+                m_blockMap.push( blockData->encodedOffsetInBits, blockData->encodedSizeInBits, blockData->dataSize );
+
+                /* EOS blocks have a different magic and are not found by the block finder (:204-238) */
+                if ( !blockData->isEndOfFile ) {
+                    const auto next = blockFetcher().readBlockHeader( blockData->encodedOffsetInBits
+                                                                      + blockData->encodedSizeInBits );
+                    if ( next.isEndOfStreamBlock ) {
+                        m_blockMap.push( next.encodedOffsetInBits, next.encodedSizeInBits, 0 );
+                        const auto nextStreamOffsetInBits = next.encodedOffsetInBits + next.encodedSizeInBits;
+                        if ( nextStreamOffsetInBits < m_source->sizeInBits() ) {
+                            if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(),
+                                                                nextStreamOffsetInBits ) == 0 ) {
+                                std::cerr << "[Warning] Trailing garbage after EOF ignored!\n";
+                                m_blockFinder->finalize( m_blockMap.dataBlockCount() );
+                            }
+                        }
+                    }
+                }
+                blockInfo = m_blockMap.findDataOffset( m_currentPosition );
+                if ( !blockInfo.contains( m_currentPosition ) ) {
+                    continue;
+                }
+            } else {
+                blockData = blockFetcher().get( blockInfo.encodedOffsetInBits );
+            }
+
+            const auto offsetInBlock = m_currentPosition - blockInfo.decodedOffsetInBytes;
+            if ( offsetInBlock >= blockData->dataSize ) {
+                fail( MI355X_BZ2_ERR_LOGIC, "Block does not contain the requested offset even though it "
+                                            "shouldn't be according to block map!" );
+            }
+            const auto nBytesToDecode = std::min( blockData->dataSize - offsetInBlock, nBytesToRead - nBytesDecoded );
+            if ( writeFunctor ) {
+                writeFunctor( blockData->data() + offsetInBlock, nBytesToDecode );
+            }
+            nBytesDecoded += nBytesToDecode;
+            m_currentPosition += nBytesToDecode;
+        }
+        return nBytesDecoded;
+    }
+
+    /** BZ2ReaderInterface::read( fd, buffer, n ), BZ2ReaderInterface.hpp:35-57 + writeAll, FileUtils.hpp:803-826 */
+    size_t
+    read( int outputFileDescriptor, char* outputBuffer, size_t nBytesToRead )
+    {
+        if ( ( outputFileDescriptor < 0 ) && ( outputBuffer == nullptr ) ) {
+            return read( WriteFunctor(), nBytesToRead );
+        }
+        uint64_t nBytesDecoded = 0;
+        const WriteFunctor writeFunctor = [&] ( const void* buffer, uint64_t size ) {
+            if ( outputFileDescriptor >= 0 ) {
+                const auto* p = static_cast<const uint8_t*>( buffer );
+                uint64_t written = 0;
+                while ( written < size ) {
+                    const auto n = ::write( outputFileDescriptor, p + written,
+                                            (size_t)std::min<uint64_t>( size - written, 1u << 30 ) );
+                    if ( n <= 0 ) {
+                        if ( n < 0 && errno == EINTR ) continue;
+                        fail( MI355X_BZ2_ERR_IO, std::string( "Failed to write all bytes because of: " ) + strerror( errno ) );
+                    }
+                    written += (uint64_t)n;
+                }
+            }
+            if ( outputBuffer != nullptr ) {
+                std::memcpy( outputBuffer + nBytesDecoded, buffer, size );
+            }
+            nBytesDecoded += size;
+        };
+        return read( writeFunctor, nBytesToRead );
+    }
+
+    /** ParallelBZ2Reader::seek, ParallelBZ2Reader.hpp:271-325 */
+    size_t
+    seek( long long int offset, int origin )
+    {
+        if ( closed() ) {
+            fail( MI355X_BZ2_ERR_CLOSED, "You may not call seek on closed ParallelBZ2Reader!" );
+        }
+        if ( origin == SEEK_END ) {
+            if ( !m_blockMap.finalized() ) {
+                read( WriteFunctor() );
+            }
+        }
+        const auto positiveOffset = effectiveOffset( offset, origin );
+        if ( positiveOffset == tell() ) {
+            return positiveOffset;
+        }
+        if ( positiveOffset < tell() ) {
+            m_atEndOfFile = false;
+            m_currentPosition = positiveOffset;
+            return positiveOffset;
+        }
+        const auto blockInfo = m_blockMap.findDataOffset( positiveOffset );
+        if ( positiveOffset < blockInfo.decodedOffsetInBytes ) {
+            fail( MI355X_BZ2_ERR_LOGIC, "Block map returned unwanted block!" );
+        }
+        if ( blockInfo.contains( positiveOffset ) ) {
+            m_atEndOfFile = false;
+            m_currentPosition = positiveOffset;
+            return tell();
+        }
+        if ( m_blockMap.finalized() ) {
+            m_atEndOfFile = true;
+            m_currentPosition = m_blockMap.back().second;
+            return tell();
+        }
+        m_atEndOfFile = false;
+        m_currentPosition = blockInfo.decodedOffsetInBytes + blockInfo.decodedSizeInBytes;
+        read( WriteFunctor(), positiveOffset - tell() );
+        return tell();
+    }
+
+    [[nodiscard]] bool
+    blockOffsetsComplete() const
+    {
+        return m_blockMap.finalized();
+    }
+
+    /** :339-350 */
+    [[nodiscard]] std::map<size_t, size_t>
+    blockOffsets()
+    {
+        if ( !m_blockMap.finalized() ) {
+            read( WriteFunctor() );
+            if ( !m_blockMap.finalized() || !blockFinder().finalized() ) {
+                fail( MI355X_BZ2_ERR_LOGIC, "Reading everything should have finalized the block map!" );
+            }
+        }
+        return m_blockMap.blockOffsets();
+    }
+
+    [[nodiscard]] std::map<size_t, size_t>
+    availableBlockOffsets() const
+    {
+        return m_blockMap.blockOffsets();
+    }
+
+    /** :365-378 */
+    void
+    setBlockOffsets( const std::map<size_t, size_t>& offsets )
+    {
+        if ( offsets.empty() ) {
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "May not clear offsets. Construct a new ParallelBZ2Reader instead!" );
+        }
+        setBlockFinderOffsets( offsets );
+        if ( offsets.size() < 2 ) {
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT,
+                  "Block offset map must contain at least one valid block and one EOS block!" );
+        }
+        m_blockMap.setBlockOffsets( offsets );
+    }
+
+    /** :385-393 */
+    [[nodiscard]] size_t
+    tellCompressed() const
+    {
+        const auto blockInfo = m_blockMap.findDataOffset( m_currentPosition );
+        if ( blockInfo.contains( m_currentPosition ) ) {
+            return blockInfo.encodedOffsetInBits;
+        }
+        return m_blockMap.empty() ? 0 : m_blockMap.back().first;
+    }
+
+    /** :404-409 */
+    void
+    joinThreads()
+    {
+        m_blockFetcher.reset();
+        m_blockFinder.reset();
+    }
+
+    [[nodiscard]] mi355x_bz2_reader_stats
+    statistics() const
+    {
+        return m_blockFetcher ? m_blockFetcher->statistics() : mi355x_bz2_reader_stats{};
+    }
+
+private:
+    [[nodiscard]] size_t
+    effectiveOffset( long long int offset, int origin ) const
+    {
+        /* FileReader::effectiveOffset, src/core/filereader/FileReader.hpp:110-140 */
+        long long int base = 0;
+        switch ( origin ) {
+        case SEEK_SET: base = 0; break;
+        case SEEK_CUR: base = (long long int)tell(); break;
+        case SEEK_END:
+        {
+            const auto fileSize = size();
+            if ( !fileSize ) fail( MI355X_BZ2_ERR_LOGIC, "File size is not available to seek from end!" );
+            base = (long long int)*fileSize;
+            break;
+        }
+        default: fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "Invalid seek origin supplied" );
+        }
+        auto target = base + offset;
+        if ( target < 0 ) target = 0;
+        const auto fileSize = size();
+        if ( fileSize && ( (size_t)target > *fileSize ) ) {
+            target = (long long int)*fileSize;
+        }
+        return (size_t)target;
+    }
+
+    /** :412-433 */
+    BlockFinder&
+    blockFinder()
+    {
+        if ( m_blockFinder ) {
+            return *m_blockFinder;
+        }
+        const unsigned cores = std::max( 1u, std::thread::hardware_concurrency() );
+        /* look-ahead 3 * hardware_concurrency in the reference (BlockFinder.hpp:213); a GPU batch wants more */
+        const size_t lookAhead = std::max<size_t>( 3 * cores, 4 * m_parallelization );
+        m_blockFinder = std::make_shared<BlockFinder>( m_source->bytes(), m_source->size(), MI355X_BZ2_MAGIC_BLOCK,
+                                                       lookAhead, std::min( 8u, std::max( 1u, cores / 2 ) ) );
+        if ( m_blockMap.finalized() ) {
+            setBlockFinderOffsets( m_blockMap.blockOffsets() );
+        }
+        return *m_blockFinder;
+    }
+
+    /** :435-454 */
+    GpuBlockFetcher&
+    blockFetcher()
+    {
+        if ( m_blockFetcher ) {
+            return *m_blockFetcher;
+        }
+        if ( !blockFinder().finalized() ) {
+            blockFinder().startThreads();
+        }
+        m_blockFetcher = std::make_unique<GpuBlockFetcher>( m_source, m_blockFinder, m_parallelization, m_device );
+        return *m_blockFetcher;
+    }
+
+    /** :456-475 */
+    void
+    setBlockFinderOffsets( const std::map<size_t, size_t>& offsets )
+    {
+        if ( offsets.empty() ) {
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "A non-empty list of block offsets is required!" );
+        }
+        std::deque<size_t> encodedBlockOffsets;
+        for ( auto it = offsets.begin(), nit = std::next( offsets.begin() ); nit != offsets.end(); ++it, ++nit ) {
+            if ( it->second != nit->second ) {
+                encodedBlockOffsets.push_back( it->first );
+            }
+        }
+        blockFinder().setBlockOffsets( std::move( encodedBlockOffsets ) );
+    }
+
+private:
+    std::shared_ptr<Source> m_source;
+    const size_t m_parallelization;
+    const int m_device;
+    size_t m_currentPosition{ 0 };
+    bool m_atEndOfFile{ false };
+
+    std::shared_ptr<BlockFinder> m_blockFinder;
+    BlockMap m_blockMap;
+    std::unique_ptr<GpuBlockFetcher> m_blockFetcher;
+};
+}  // namespace mi355x
+
+/* ================================================================================================ C ABI */
+struct mi355x_bz2_reader
+{
+    std::unique_ptr<mi355x::ParallelReader> reader;
+    std::string lastError;
+};
+
+namespace
+{
+template<typename Functor>
+int
+guarded( mi355x_bz2_reader* r, const Functor& functor )
+{
+    if ( r == nullptr || !r->reader ) {
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    try {
+        functor( *r->reader );
+        return MI355X_BZ2_OK;
+    } catch ( const mi355x::Bz2Exception& e ) {
+        r->lastError = e.what();
+        return e.status;
+    } catch ( const std::invalid_argument& e ) {
+        r->lastError = e.what();
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    } catch ( const std::exception& e ) {
+        r->lastError = e.what();
+        return MI355X_BZ2_ERR_LOGIC;
+    }
+}
+
+template<typename MakeSource>
+int
+openReader( const MakeSource& makeSource, uint32_t parallelization, int32_t device, mi355x_bz2_reader** out )
+{
+    if ( out == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    try {
+        auto source = makeSource();
+        auto* r = new mi355x_bz2_reader();
+        r->reader = std::make_unique<mi355x::ParallelReader>( std::move( source ), parallelization, device );
+        *out = r;
+        return MI355X_BZ2_OK;
+    } catch ( const mi355x::Bz2Exception& e ) {
+        std::fprintf( stderr, "mi355x_bz2_reader_open: %s\n", e.what() );
+        return e.status;
+    } catch ( const std::exception& e ) {
+        std::fprintf( stderr, "mi355x_bz2_reader_open: %s\n", e.what() );
+        return MI355X_BZ2_ERR_LOGIC;
+    }
+}
+
+int
+copyOffsets( const std::map<size_t, size_t>& offsets, uint64_t* bits, uint64_t* bytes, uint64_t capacity, uint64_t* n )
+{
+    if ( n != nullptr ) *n = offsets.size();
+    if ( capacity == 0 ) return MI355X_BZ2_OK;
+    if ( bits == nullptr || bytes == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    uint64_t i = 0;
+    for ( const auto& [b, d] : offsets ) {
+        if ( i >= capacity ) break;
+        bits[i] = b;
+        bytes[i] = d;
+        ++i;
+    }
+    return MI355X_BZ2_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int
+mi355x_bz2_reader_open_path( const char* path, uint32_t parallelization, int32_t device, mi355x_bz2_reader** r )
+{
+    if ( path == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    return openReader( [path] () { return mi355x::Source::fromPath( path ); }, parallelization, device, r );
+}
+
+int
+mi355x_bz2_reader_open_fd( int fd, uint32_t parallelization, int32_t device, mi355x_bz2_reader** r )
+{
+    /* dup so that the caller's descriptor stays usable (StandardFileReader(int), filereader/Standard.hpp:50-62) */
+    return openReader( [fd] () {
+        const int copy = dup( fd );
+        if ( copy < 0 ) mi355x::fail( MI355X_BZ2_ERR_IO, std::string( "dup: " ) + strerror( errno ) );
+        return mi355x::Source::fromFd( copy, true );
+    }, parallelization, device, r );
+}
+
+int
+mi355x_bz2_reader_open_memory( const uint8_t* bytes, uint64_t size, uint32_t parallelization, int32_t device,
+                               mi355x_bz2_reader** r )
+{
+    if ( bytes == nullptr && size > 0 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    return openReader( [bytes, size] () { return mi355x::Source::fromMemory( bytes, size ); }, parallelization, device, r );
+}
+
+void
+mi355x_bz2_reader_close( mi355x_bz2_reader* r )
+{
+    if ( r == nullptr ) return;
+    if ( r->reader ) {
+        try { r->reader->close(); } catch ( ... ) {}
+    }
+    delete r;
+}
+
+const char*
+mi355x_bz2_reader_last_error( const mi355x_bz2_reader* r )
+{
+    return r != nullptr ? r->lastError.c_str() : "null reader";
+}
+
+int
+mi355x_bz2_reader_read( mi355x_bz2_reader* r, int fd, void* buffer, uint64_t nBytes, uint64_t* nRead )
+{
+    if ( nRead != nullptr ) *nRead = 0;
+    return guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+        const auto n = reader.read( fd, static_cast<char*>( buffer ), (size_t)nBytes );
+        if ( nRead != nullptr ) *nRead = n;
+    } );
+}
+
+int
+mi355x_bz2_reader_seek( mi355x_bz2_reader* r, int64_t offset, int whence, uint64_t* newPosition )
+{
+    return guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+        const auto p = reader.seek( offset, whence );
+        if ( newPosition != nullptr ) *newPosition = p;
+    } );
+}
+
+uint64_t
+mi355x_bz2_reader_tell( const mi355x_bz2_reader* r )
+{
+    uint64_t result = 0;
+    guarded( const_cast<mi355x_bz2_reader*>( r ), [&] ( mi355x::ParallelReader& reader ) { result = reader.tell(); } );
+    return result;
+}
+
+int
+mi355x_bz2_reader_eof( const mi355x_bz2_reader* r )
+{
+    return ( r != nullptr && r->reader && r->reader->eof() ) ? 1 : 0;
+}
+
+int
+mi355x_bz2_reader_closed( const mi355x_bz2_reader* r )
+{
+    return ( r == nullptr || !r->reader || r->reader->closed() ) ? 1 : 0;
+}
+
+int
+mi355x_bz2_reader_size( const mi355x_bz2_reader* r, uint64_t* size )
+{
+    if ( r == nullptr || !r->reader ) return 0;
+    const auto s = r->reader->size();
+    if ( !s ) return 0;
+    if ( size != nullptr ) *size = *s;
+    return 1;
+}
+
+uint64_t
+mi355x_bz2_reader_tell_compressed( const mi355x_bz2_reader* r )
+{
+    uint64_t result = 0;
+    guarded( const_cast<mi355x_bz2_reader*>( r ),
+             [&] ( mi355x::ParallelReader& reader ) { result = reader.tellCompressed(); } );
+    return result;
+}
+
+int
+mi355x_bz2_reader_block_offsets_complete( const mi355x_bz2_reader* r )
+{
+    return ( r != nullptr && r->reader && r->reader->blockOffsetsComplete() ) ? 1 : 0;
+}
+
+int
+mi355x_bz2_reader_block_offsets( mi355x_bz2_reader* r, uint64_t* bits, uint64_t* bytes, uint64_t capacity, uint64_t* n )
+{
+    int inner = MI355X_BZ2_OK;
+    const int rc = guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+        inner = copyOffsets( reader.blockOffsets(), bits, bytes, capacity, n );
+    } );
+    return rc != MI355X_BZ2_OK ? rc : inner;
+}
+
+int
+mi355x_bz2_reader_available_block_offsets( const mi355x_bz2_reader* r, uint64_t* bits, uint64_t* bytes,
+                                           uint64_t capacity, uint64_t* n )
+{
+    int inner = MI355X_BZ2_OK;
+    const int rc = guarded( const_cast<mi355x_bz2_reader*>( r ), [&] ( mi355x::ParallelReader& reader ) {
+        inner = copyOffsets( reader.availableBlockOffsets(), bits, bytes, capacity, n );
+    } );
+    return rc != MI355X_BZ2_OK ? rc : inner;
+}
+
+int
+mi355x_bz2_reader_set_block_offsets( mi355x_bz2_reader* r, const uint64_t* bits, const uint64_t* bytes, uint64_t n )
+{
+    if ( n > 0 && ( bits == nullptr || bytes == nullptr ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    return guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+        std::map<size_t, size_t> offsets;
+        for ( uint64_t i = 0; i < n; ++i ) {
+            offsets.emplace( bits[i], bytes[i] );
+        }
+        reader.setBlockOffsets( offsets );
+    } );
+}
+
+int
+mi355x_bz2_reader_join_threads( mi355x_bz2_reader* r )
+{
+    return guarded( r, [] ( mi355x::ParallelReader& reader ) { reader.joinThreads(); } );
+}
+
+int
+mi355x_bz2_reader_statistics( const mi355x_bz2_reader* r, mi355x_bz2_reader_stats* stats )
+{
+    if ( stats == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    return guarded( const_cast<mi355x_bz2_reader*>( r ),
+                    [&] ( mi355x::ParallelReader& reader ) { *stats = reader.statistics(); } );
+}
+
+}  // extern "C"

@@ -340,7 +340,7 @@ orc_read_stream_header( const uint8_t* file, uint64_t file_size, uint64_t bit_of
 int
 orc_read_block_header( const uint8_t* file, uint64_t file_size, uint64_t bit_offset, orc_block_result* res )
 {
-    blk* s = (blk*)malloc( sizeof( blk ) );
+    blk* s = (blk*)calloc( 1, sizeof( blk ) );
     memset( res, 0, sizeof( *res ) );
     const int err = read_block_header( s, file, file_size, bit_offset );
     fill_result( s, res, err );
@@ -356,7 +356,7 @@ orc_decode_block( const uint8_t* file, uint64_t file_size, uint64_t bit_offset,
     crc_init();
     memset( res, 0, sizeof( *res ) );
     res->computed_crc = 0xFFFFFFFFu;   /* BlockData::calculatedCRC default, BZ2BlockFetcher.hpp:33 */
-    blk* s = (blk*)malloc( sizeof( blk ) );
+    blk* s = (blk*)calloc( 1, sizeof( blk ) );
     uint32_t* dbuf = NULL;
     int err = read_block_header( s, file, file_size, bit_offset );
     if ( err != ORC_OK || s->eos ) goto done;
@@ -392,7 +392,9 @@ orc_decode_block( const uint8_t* file, uint64_t file_size, uint64_t bit_offset,
             }
             if ( runPos != 0 ) {
                 runPos = 0;
-                if ( dbufCount + hh > DBUF_SIZE ) { err = ORC_ERR_RUN_OVERFLOW; goto done; }
+                /* The reference adds in uint32 (bzip2.hpp:751): a wrapped sum would pass its check and then overrun
+                 * dbuf (undefined behaviour).  The only defined outcome is the overflow error, so widen the sum. */
+                if ( (uint64_t)dbufCount + hh > DBUF_SIZE ) { err = ORC_ERR_RUN_OVERFLOW; goto done; }
                 const uint8_t uc = s->symbol_to_byte[mtf[0]];
                 byteCount[uc] += hh;
                 while ( hh-- != 0 ) dbuf[dbufCount++] = uc;
