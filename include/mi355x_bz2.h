@@ -97,15 +97,18 @@ typedef struct mi355x_bz2_block_result {
     int32_t  status;                /* mi355x_bz2_status */
 } mi355x_bz2_block_result;
 
-/* Device time of the last decode_batch per pipeline stage, measured with HIP events on the ctx stream. */
+/* Device time of every kernel launch of the last decode_batch, measured with HIP events recorded on the ctx stream
+ * around each launch (the stream the kernels run on).  Kernel i is named by mi355x_bz2_kernel_name(i). */
+#define MI355X_BZ2_MAX_KERNELS 16
 typedef struct mi355x_bz2_timings {
-    float ms_total;          /* first kernel start .. last kernel end */
-    float ms_huffman;        /* header parse + Huffman + MTF + RLE2  -> L column */
-    float ms_bwt_build;      /* histogram + rank -> packed LF table */
-    float ms_walk;           /* multi-segment permutation walk (both passes) + segment linking */
-    float ms_rle_crc;        /* RLE1 sizing, expansion and CRC */
-    float ms_reserved[3];
+    float    ms_total;                           /* first kernel start .. last kernel end (includes the one host sync) */
+    float    ms_kernel_sum;                      /* sum of ms_kernel[] */
+    uint32_t n_kernels;
+    uint32_t reserved;
+    float    ms_kernel[MI355X_BZ2_MAX_KERNELS];
 } mi355x_bz2_timings;
+
+const char* mi355x_bz2_kernel_name( uint32_t index );
 
 /* Create / destroy a decoder context bound to one GPU and one HIP stream.
  * Fails with MI355X_BZ2_ERR_NO_DEVICE when no usable gfx950 device exists: there is no CPU fallback. */

@@ -42,12 +42,17 @@ class BlockResult(ctypes.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+MAX_KERNELS = 16
+
+
 class Timings(ctypes.Structure):
-    _fields_ = [("ms_total", ctypes.c_float), ("ms_huffman", ctypes.c_float), ("ms_bwt_build", ctypes.c_float),
-                ("ms_walk", ctypes.c_float), ("ms_rle_crc", ctypes.c_float), ("ms_reserved", ctypes.c_float * 3)]
+    _fields_ = [("ms_total", ctypes.c_float), ("ms_kernel_sum", ctypes.c_float), ("n_kernels", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("ms_kernel", ctypes.c_float * MAX_KERNELS)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k in ("ms_total", "ms_huffman", "ms_bwt_build", "ms_walk", "ms_rle_crc")}
+        names = [lib().mi355x_bz2_kernel_name(i).decode() for i in range(self.n_kernels)]
+        return {"ms_total": self.ms_total, "ms_kernel_sum": self.ms_kernel_sum,
+                "kernels": {names[i]: self.ms_kernel[i] for i in range(self.n_kernels)}}
 
 
 class ReaderStats(ctypes.Structure):
@@ -76,6 +81,7 @@ SYMBOLS = [
     ("mi355x_bz2_output_device", _vp, [_vp]),
     ("mi355x_bz2_copy_output", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     ("mi355x_bz2_last_timings", ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
+    ("mi355x_bz2_kernel_name", ctypes.c_char_p, [ctypes.c_uint32]),
     ("mi355x_bz2_stream", _vp, [_vp]),
     ("mi355x_bz2_debug_copy_stage", ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_int, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_find_magic", ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _u64p,

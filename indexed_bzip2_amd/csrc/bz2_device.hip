@@ -55,7 +55,8 @@ struct mi355x_bz2_ctx
     uint32_t lastBlocks{ 0 };
 
     CrcConsts crc{};
-    hipEvent_t ev[6]{};
+    hipEvent_t ev[2 * MI355X_BZ2_MAX_KERNELS]{};
+    uint32_t nKernels{ 0 };
     mi355x_bz2_timings timings{};
 };
 
@@ -162,7 +163,31 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 }
 }  // namespace
 
+namespace
+{
+const char* const KERNEL_NAMES[] = {
+    "k_stage1", "k_bwt_build", "k_walk<false>", "k_link", "k_walk<true>", "k_replicate", "k_rle<false>",
+    "k_rle<true>", "k_crc"
+};
+constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
+static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
+}  // namespace
+
+/* record an event pair around one launch so that every kernel gets its own device duration */
+#define TIMED_LAUNCH( ctx, index, ... )                                           \
+    do {                                                                          \
+        HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[2 * ( index )], ( ctx )->stream ) );     \
+        hipLaunchKernelGGL( __VA_ARGS__ );                                        \
+        HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[2 * ( index ) + 1], ( ctx )->stream ) ); \
+    } while ( 0 )
+
 extern "C" {
+
+const char*
+mi355x_bz2_kernel_name( uint32_t index )
+{
+    return index < N_KERNELS ? KERNEL_NAMES[index] : "";
+}
 
 const char*
 mi355x_bz2_status_string( int status )
@@ -329,21 +354,17 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     std::memcpy( c->hOffsets, offsets, (size_t)n * sizeof( uint64_t ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
 
-    HIP_TRY( c, hipEventRecord( c->ev[0], c->stream ) );
-    hipLaunchKernelGGL( k_stage1, dim3( n ), dim3( 64 ), 0, c->stream,
-                        reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dSel, c->dL );
-    HIP_TRY( c, hipEventRecord( c->ev[1], c->stream ) );
-    hipLaunchKernelGGL( k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
-    HIP_TRY( c, hipEventRecord( c->ev[2], c->stream ) );
+    TIMED_LAUNCH( c, 0, k_stage1, dim3( n ), dim3( 64 ), 0, c->stream,
+                  reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dSel, c->dL );
+    TIMED_LAUNCH( c, 1, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
     const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );
-    hipLaunchKernelGGL( k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
-                        c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-    hipLaunchKernelGGL( k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
-    hipLaunchKernelGGL( k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
-                        c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-    hipLaunchKernelGGL( k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
-    HIP_TRY( c, hipEventRecord( c->ev[3], c->stream ) );
-    hipLaunchKernelGGL( k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
+    TIMED_LAUNCH( c, 2, k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
+                  c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+    TIMED_LAUNCH( c, 3, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
+    TIMED_LAUNCH( c, 4, k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
+                  c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+    TIMED_LAUNCH( c, 5, k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
+    TIMED_LAUNCH( c, 6, k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
     HIP_TRY( c, hipGetLastError() );
 
     /* sizes -> host: output offsets are an exclusive scan of the decoded sizes (ragged, gap-free) */
@@ -357,9 +378,8 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     rc = ensureOutput( c, total );
     if ( rc != MI355X_BZ2_OK ) return rc;
     HIP_TRY( c, hipMemcpyAsync( c->dMeta, c->hMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) );
-    hipLaunchKernelGGL( k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
-    hipLaunchKernelGGL( k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
-    HIP_TRY( c, hipEventRecord( c->ev[4], c->stream ) );
+    TIMED_LAUNCH( c, 7, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
+    TIMED_LAUNCH( c, 8, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
     HIP_TRY( c, hipGetLastError() );
     HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
@@ -386,11 +406,14 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
 
     float ms = 0;
     c->timings = {};
-    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[4] ) == hipSuccess ) c->timings.ms_total = ms;
-    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[1] ) == hipSuccess ) c->timings.ms_huffman = ms;
-    if ( hipEventElapsedTime( &ms, c->ev[1], c->ev[2] ) == hipSuccess ) c->timings.ms_bwt_build = ms;
-    if ( hipEventElapsedTime( &ms, c->ev[2], c->ev[3] ) == hipSuccess ) c->timings.ms_walk = ms;
-    if ( hipEventElapsedTime( &ms, c->ev[3], c->ev[4] ) == hipSuccess ) c->timings.ms_rle_crc = ms;
+    c->timings.n_kernels = N_KERNELS;
+    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[2 * N_KERNELS - 1] ) == hipSuccess ) c->timings.ms_total = ms;
+    for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
+        if ( hipEventElapsedTime( &ms, c->ev[2 * k], c->ev[2 * k + 1] ) == hipSuccess ) {
+            c->timings.ms_kernel[k] = ms;
+            c->timings.ms_kernel_sum += ms;
+        }
+    }
     return MI355X_BZ2_OK;
 }
 

@@ -77,9 +77,9 @@ def _xml_vocab():
 def xml(n, rng):
     tags, words, vocab = _xml_vocab()
     nwords = n // 5 + 64
-    kind = rng.random(nwords) < 0.3
+    kind = rng.random(nwords) < 0.45
     idx = np.where(kind, rng.integers(0, len(tags), nwords),
-                   len(tags) + np.minimum(rng.zipf(1.1, nwords) - 1, len(words) - 1))
+                   len(tags) + np.minimum(rng.zipf(1.35, nwords) - 1, len(words) - 1))
     return _words_to_bytes(vocab, idx, [32, 32, 10, 32, 61, 34], rng)[:n]
 
 
@@ -116,7 +116,10 @@ def database(n, rng):
     vals = rng.integers(0, 100000, k)
     for d in range(6):
         out[:, 30 - d] = 48 + (vals // 10**d) % 10
-    out[:, 32:60] = rng.choice(np.frombuffer(b"0123456789ABCDEF  ", dtype=np.uint8), (k, 28))
+    codes = np.frombuffer(b"".join(_vocab(None, 512, 28, 29, b"0123456789ABCDEF  ")), dtype=np.uint8).reshape(512, 28)
+    out[:, 32:60] = codes[np.minimum(rng.zipf(1.2, k) - 1, 511)]
+    flip = rng.random(k) < 0.3
+    out[flip, 40:46] = rng.choice(np.frombuffer(b"0123456789", dtype=np.uint8), (int(flip.sum()), 6))
     out[:, 63] = 10
     return out.reshape(-1)[:n]
 
@@ -124,12 +127,12 @@ def database(n, rng):
 def binary(n, rng):
     """Executable-like: opcode-ish bytes from a skewed table mixed with small little-endian immediates."""
     table = rng.permutation(256).astype(np.uint8)
-    ops = table[np.minimum(rng.zipf(1.25, n) - 1, 255)]
-    imm = rng.random(n) < 0.18
+    ops = table[np.minimum(rng.zipf(1.9, n) - 1, 255)]
+    imm = rng.random(n) < 0.30
     ops[imm] = np.where(rng.random(int(imm.sum())) < 0.6, 0, 255).astype(np.uint8)
     # repeated code fragments
     frag = 4096
-    for start in rng.integers(0, max(1, n - 2 * frag), n // (frag * 6)):
+    for start in rng.integers(0, max(1, n - 2 * frag), n // (frag * 2)):
         src = int(rng.integers(0, max(1, n - frag)))
         ops[start:start + frag] = ops[src:src + frag]
     return ops
@@ -160,29 +163,38 @@ def noise(n, rng):
 
 
 # (generator, share of the corpus) -- shares roughly follow Silesia's file sizes by type
-MIX = [(prose, 0.24), (xml, 0.10), (source, 0.12), (database, 0.12), (binary, 0.20), (pcm16, 0.11), (dna, 0.05),
-       (noise, 0.06)]
+MIX = [(prose, 0.25), (xml, 0.11), (source, 0.13), (database, 0.12), (binary, 0.19), (pcm16, 0.11), (dna, 0.05),
+       (noise, 0.04)]
 
 
-def generate(n_bytes, seed=0x51E51A, segment=6_000_000):
-    """Interleave ~6 MB segments of each type (files of a tar) up to n_bytes."""
-    rng = np.random.default_rng(seed)
-    parts = []
-    total = 0
+def generate(n_bytes, seed=0x51E51A, segment=6_000_000, threads=8):
+    """Interleave ~6 MB segments of each type (like the files of a tar) up to n_bytes.  Segments are planned with one
+    rng and generated independently (own seeded rng each) on a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    plan_rng = np.random.default_rng(seed)
     gens = [g for g, _ in MIX]
     shares = np.array([s for _, s in MIX])
     shares = shares / shares.sum()
     produced = np.zeros(len(gens))
+    plan = []
+    total = 0
     while total < n_bytes:
-        # pick the type that is furthest below its share
-        deficit = shares * (total + segment) - produced
+        deficit = shares * (total + segment) - produced   # the type furthest below its share goes next
         k = int(np.argmax(deficit))
-        seglen = int(min(segment * (0.5 + rng.random()), n_bytes - total))
-        seglen = max(seglen, 1)
-        part = np.ascontiguousarray(gens[k](seglen, rng)[:seglen])
-        parts.append(part)
-        produced[k] += len(part)
-        total += len(part)
+        seglen = max(1, int(min(segment * (0.5 + plan_rng.random()), n_bytes - total)))
+        plan.append((k, seglen, int(plan_rng.integers(0, 2**31))))
+        produced[k] += seglen
+        total += seglen
+    # build the shared vocabularies before going parallel
+    for g in gens:
+        g(1000, np.random.default_rng(1))
+
+    def make(item):
+        k, seglen, sd = item
+        return np.ascontiguousarray(gens[k](seglen, np.random.default_rng(sd))[:seglen])
+
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(make, plan))
     return np.concatenate(parts)[:n_bytes]
 
 
