@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -17,6 +18,7 @@
 
 #include "../../include/mi355x_bz2.h"
 #include "bz2_kernels.hip.h"
+#include "bz2_stage1.hip.h"
 
 using namespace bz2gpu;
 
@@ -39,6 +41,10 @@ struct mi355x_bz2_ctx
     uint64_t* dOffsets{ nullptr };
     BlockMeta* dMeta{ nullptr };
     uint8_t* dSel{ nullptr };
+    uint16_t* dSym{ nullptr };
+    uint8_t* dStb{ nullptr };
+    HuffMeta* dHmeta{ nullptr };
+    bool useV1Stage1{ false };
     uint8_t* dL{ nullptr };
     uint32_t* dTab{ nullptr };
     uint8_t* dR{ nullptr };
@@ -113,6 +119,9 @@ freeScratch( mi355x_bz2_ctx* c )
     (void)hipFree( c->dOffsets ); c->dOffsets = nullptr;
     (void)hipFree( c->dMeta ); c->dMeta = nullptr;
     (void)hipFree( c->dSel ); c->dSel = nullptr;
+    (void)hipFree( c->dSym ); c->dSym = nullptr;
+    (void)hipFree( c->dStb ); c->dStb = nullptr;
+    (void)hipFree( c->dHmeta ); c->dHmeta = nullptr;
     (void)hipFree( c->dL ); c->dL = nullptr;
     (void)hipFree( c->dTab ); c->dTab = nullptr;
     (void)hipFree( c->dR ); c->dR = nullptr;
@@ -136,6 +145,9 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dMeta, (size_t)cap * sizeof( BlockMeta ) ) );
     HIP_TRY( c, hipMalloc( &c->dSel, (size_t)cap * SEL_STRIDE ) );
+    HIP_TRY( c, hipMalloc( &c->dSym, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dStb, (size_t)cap * 256 ) );
+    HIP_TRY( c, hipMalloc( &c->dHmeta, (size_t)cap * sizeof( HuffMeta ) ) );
     HIP_TRY( c, hipMalloc( &c->dL, (size_t)cap * L_STRIDE + 256 ) );
     HIP_TRY( c, hipMalloc( &c->dTab, (size_t)cap * TAB_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dR, (size_t)cap * L_STRIDE + 256 ) );
@@ -166,7 +178,7 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 namespace
 {
 const char* const KERNEL_NAMES[] = {
-    "k_stage1", "k_bwt_build", "k_walk<false>", "k_link", "k_walk<true>", "k_replicate", "k_rle<false>",
+    "k_huff", "k_mtf", "k_bwt_build", "k_walk<false>", "k_link", "k_walk<true>", "k_replicate", "k_rle<false>",
     "k_rle<true>", "k_crc"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
@@ -249,6 +261,10 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
     auto* c = new mi355x_bz2_ctx();
     c->device = device;
     c->flags = config != nullptr ? config->flags : 0;
+    {
+        const char* v1 = std::getenv( "MI355X_BZ2_V1_STAGE1" );
+        c->useV1Stage1 = v1 != nullptr && v1[0] == '1';
+    }
     if ( hipSetDevice( device ) != hipSuccess
          || hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
         delete c;
@@ -325,7 +341,24 @@ mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_
     if ( c == nullptr || ( deviceBytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     if ( ( reinterpret_cast<uintptr_t>( deviceBytes ) & 3u ) != 0 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex );
-    c->dIn = static_cast<const uint8_t*>( deviceBytes );
+    /* The kernels read whole 16-byte windows without bounds checks, so the bytes are copied (device to device, once)
+     * into ctx-owned memory that is zero padded past the end. */
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    const uint64_t padded = ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256;
+    if ( padded > c->dInOwnedCapacity ) {
+        HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+        (void)hipFree( c->dInOwned );
+        c->dInOwned = nullptr;
+        c->dInOwnedCapacity = 0;
+        HIP_TRY( c, hipMalloc( &c->dInOwned, padded ) );
+        c->dInOwnedCapacity = padded;
+    }
+    HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0, padded - ( size & ~uint64_t( 255 ) ), c->stream ) );
+    if ( size > 0 ) {
+        HIP_TRY( c, hipMemcpyAsync( c->dInOwned, deviceBytes, size, hipMemcpyDeviceToDevice, c->stream ) );
+    }
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    c->dIn = c->dInOwned;
     c->inSize = size;
     return MI355X_BZ2_OK;
 }
@@ -354,17 +387,28 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     std::memcpy( c->hOffsets, offsets, (size_t)n * sizeof( uint64_t ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
 
-    TIMED_LAUNCH( c, 0, k_stage1, dim3( n ), dim3( 64 ), 0, c->stream,
-                  reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dSel, c->dL );
-    TIMED_LAUNCH( c, 1, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
+    if ( c->useV1Stage1 ) {
+        /* fused v1 kernel kept for A/B comparison (MI355X_BZ2_V1_STAGE1=1) */
+        TIMED_LAUNCH( c, 0, k_stage1, dim3( n ), dim3( 64 ), 0, c->stream,
+                      reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dSel, c->dL );
+        HIP_TRY( c, hipEventRecord( c->ev[2], c->stream ) );
+        HIP_TRY( c, hipEventRecord( c->ev[3], c->stream ) );
+    } else {
+        TIMED_LAUNCH( c, 0, k_huff, dim3( n ), dim3( 64 ), 0, c->stream,
+                      reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dHmeta, c->dSel,
+                      c->dSym, c->dStb );
+        TIMED_LAUNCH( c, 1, k_mtf, dim3( n ), dim3( MTF_THREADS ), 0, c->stream,
+                      c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL );
+    }
+    TIMED_LAUNCH( c, 2, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
     const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );
-    TIMED_LAUNCH( c, 2, k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
+    TIMED_LAUNCH( c, 3, k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
                   c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-    TIMED_LAUNCH( c, 3, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
-    TIMED_LAUNCH( c, 4, k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
+    TIMED_LAUNCH( c, 4, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
+    TIMED_LAUNCH( c, 5, k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
                   c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-    TIMED_LAUNCH( c, 5, k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
-    TIMED_LAUNCH( c, 6, k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
+    TIMED_LAUNCH( c, 6, k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
+    TIMED_LAUNCH( c, 7, k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
     HIP_TRY( c, hipGetLastError() );
 
     /* sizes -> host: output offsets are an exclusive scan of the decoded sizes (ragged, gap-free) */
@@ -378,8 +422,8 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     rc = ensureOutput( c, total );
     if ( rc != MI355X_BZ2_OK ) return rc;
     HIP_TRY( c, hipMemcpyAsync( c->dMeta, c->hMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) );
-    TIMED_LAUNCH( c, 7, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
-    TIMED_LAUNCH( c, 8, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
+    TIMED_LAUNCH( c, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
+    TIMED_LAUNCH( c, 9, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
     HIP_TRY( c, hipGetLastError() );
     HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
@@ -393,9 +437,11 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         r.data_offset = m.out_off;
         r.header_crc = m.header_crc;
         r.computed_crc = m.computed_crc;
-        r.bwt_length = m.n;
+        /* the reference (and the oracle) only know N and the symbol count once the symbol loop has completed */
+        const bool loopDone = m.status == ST_OK || m.status == ST_CRC || m.status == ST_ORIGPTR_DATA;
+        r.bwt_length = loopDone ? m.n : 0;
         r.orig_ptr = m.orig_ptr;
-        r.n_symbols = m.nsym;
+        r.n_symbols = loopDone ? m.nsym : 0;
         r.is_eos = m.is_eos;
         r.is_eof = m.is_eof;
         r.status = m.status;

@@ -1,0 +1,598 @@
+/**
+ * bz2_stage1.hip.h -- stage 1 of the block decoder split in two kernels (replaces the fused v1 k_stage1).
+ *
+ *   k_huff  one wavefront per block.  Header/selector/code-length parse as before, then the Huffman bit stream is
+ *           decoded a WINDOW at a time: every lane looks up the code that would start at "its" bit (64 consecutive
+ *           bit positions, LUTs in LDS), and the true code boundaries are found by following the chain
+ *           0 -> len -> len' ... with v_readlane on the scalar unit.  The LUT has a second 16-bit half per entry that
+ *           describes ALL codes wholly inside the 10 index bits (start mask + total advance), so one scalar step
+ *           usually skips 2-3 symbols.  Symbols (u16) go to HBM; no MTF here.
+ *           Reference: Block::readBlockData's symbol loop + HuffmanCodingShortBitsCached::decode
+ *           (src/indexed_bzip2/bzip2.hpp:709-723, src/huffman/HuffmanCodingShortBitsCached.hpp:98-150).
+ *
+ *   k_mtf   128 lanes per block, each owning a contiguous chunk of the symbol stream: RUNA/RUNB run lengths and
+ *           move-to-front (bzip2.hpp:726-790).  MTF is order dependent, so pass A runs every chunk on an identity
+ *           list (giving the chunk's permutation and output size), the permutations are composed in chunk order to
+ *           get each chunk's true start list, and pass B replays the chunk with it and writes the L column.
+ *           Each lane keeps its 256-entry list in LDS (64 dwords, lane-interleaved: conflict free).
+ */
+#pragma once
+
+#include "bz2_kernels.hip.h"
+
+namespace bz2gpu
+{
+constexpr uint32_t SYM_STRIDE = 900224;       /* u16 symbols per block (n_sym <= N + 1 <= 900001 for valid blocks) */
+constexpr uint32_t SYM_CAP = 900096;
+constexpr uint32_t MTF_THREADS = 128;
+
+/** Per-block hand-off between k_huff and k_mtf. */
+struct HuffMeta
+{
+    uint32_t n_stored;      /* symbols written to sym_buf (without the end-of-block symbol) */
+    uint32_t symbol_count;  /* bzip2 symbolCount (used byte values) */
+    int32_t  status;        /* first error of the Huffman stage (ST_OK if the end-of-block symbol was reached) */
+    uint32_t active;        /* 1 if k_mtf has work (data block whose header parsed) */
+};
+
+struct HuffShared
+{
+    uint32_t lut[6][1 << LUT_BITS];   /* lo16: {len:5, sym:9} of the code starting here (0: longer than LUT_BITS / none)
+                                         hi16: {mask:10 starts of all codes inside the index bits, adv:6 their total length} */
+    uint16_t perm[6][260];
+    uint32_t first[6][24];
+    uint32_t count[6][24];
+    uint32_t offs[6][24];
+    uint32_t running[24];
+    uint8_t  lens[6][264];
+    uint16_t bitmap[16];
+    uint8_t  sym_to_byte[256];
+    uint32_t minmax[6];
+};
+
+__global__ __launch_bounds__( 64 ) void
+k_huff( const uint32_t* __restrict__ in_words,
+        uint64_t                     in_size_bytes,
+        const uint64_t* __restrict__ offsets,
+        BlockMeta* __restrict__      meta,
+        HuffMeta* __restrict__       hmeta,
+        uint8_t*                     sel_buf,
+        uint16_t* __restrict__       sym_buf,
+        uint8_t* __restrict__        stb_buf )
+{
+    __shared__ HuffShared sh;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
+    uint16_t* const symOut = sym_buf + (size_t)b * SYM_STRIDE;
+
+    const uint64_t start = offsets[b];
+    BitRd br;
+    br.init( in_words, in_size_bytes, start );
+
+    int32_t status = ST_OK;
+    uint32_t headerCrc = 0, origPtr = 0, nsym = 0, cnt = 0;
+    int32_t isEos = 0, isEof = 0;
+    uint64_t encSize = 0;
+    uint32_t symbolCount = 0, groupCount = 0, nSel = 0;
+    uint32_t active = 0;
+
+#define FAIL( code ) do { status = br.eof ? (int32_t)ST_EOF : (int32_t)( code ); goto finish; } while ( 0 )
+
+    /* ---- Block::readBlockHeader, bzip2.hpp:479-523 ---- */
+    if ( start > br.size_bits ) {
+        br.eof = true;
+        FAIL( ST_EOF );
+    }
+    {
+        const uint64_t hi = br.read( 24 );
+        const uint64_t lo = br.read( 24 );
+        const uint64_t magic = ( hi << 24 ) | lo;
+        headerCrc = br.read( 32 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( magic == 0x177245385090ULL ) {
+            isEos = 1;
+            const uint32_t inByte = (uint32_t)( br.pos & 7 );
+            if ( inByte > 0 ) {
+                br.read( 8 - inByte );
+                if ( br.eof ) FAIL( ST_EOF );
+            }
+            encSize = br.pos - start;
+            isEof = br.pos >= br.size_bits;
+            goto finish;
+        }
+        if ( magic != 0x314159265359ULL ) FAIL( ST_BAD_MAGIC );
+        const uint32_t randomized = br.read( 1 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( randomized ) FAIL( ST_RANDOMIZED );
+        origPtr = br.read( 24 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( origPtr > MAX_N ) FAIL( ST_ORIGPTR_RANGE );
+    }
+
+    /* ---- Block::readSymbolMaps, bzip2.hpp:526-571 ---- */
+    {
+        const uint32_t used = br.read( 16 );
+        for ( uint32_t v = lane; v < 256; v += 64 ) sh.sym_to_byte[v] = 0;   /* fresh Block: zero-initialised */
+        for ( int i = 0; i < 16; ++i ) {
+            uint32_t bm = 0;
+            if ( used & ( 1u << ( 15 - i ) ) ) {
+                bm = br.read( 16 );
+            }
+            if ( lane == 0 ) sh.bitmap[i] = (uint16_t)bm;
+        }
+        __syncthreads();
+        uint32_t total = 0;
+        for ( int g = 0; g < 16; ++g ) total += __popc( sh.bitmap[g] );
+        symbolCount = total;
+        for ( uint32_t v = lane; v < 256; v += 64 ) {
+            const uint32_t g = v >> 4, j = v & 15;
+            const uint32_t bm = sh.bitmap[g];
+            if ( bm & ( 1u << ( 15 - j ) ) ) {
+                uint32_t rank = 0;
+                for ( uint32_t gg = 0; gg < g; ++gg ) rank += __popc( sh.bitmap[gg] );
+                rank += j == 0 ? 0 : __popc( bm >> ( 16 - j ) );
+                sh.sym_to_byte[rank] = (uint8_t)v;
+            }
+        }
+        __syncthreads();
+        if ( br.eof ) FAIL( ST_EOF );
+        reinterpret_cast<uint32_t*>( stb_buf + (size_t)b * 256 )[lane] =
+            reinterpret_cast<const uint32_t*>( sh.sym_to_byte )[lane];
+    }
+
+    /* ---- Block::readSelectors, bzip2.hpp:574-637 ---- */
+    {
+        groupCount = br.read( 3 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( groupCount < 2 || groupCount > 6 ) FAIL( ST_GROUP_COUNT );
+        nSel = br.read( 15 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( nSel == 0 ) FAIL( ST_SELECTOR_COUNT );
+        uint32_t mtfsel = 0x543210u;   /* nibble k = entry k */
+        uint32_t packed = 0;
+        for ( uint32_t i = 0; i < nSel; ++i ) {
+            br.refill();
+            if ( br.pos + 6 > br.size_bits ) {   /* peek<6> throws at EOF, BitReader.hpp:458-460 */
+                br.eof = true;
+                FAIL( ST_EOF );
+            }
+            const uint32_t bits6 = br.peek( 6 );
+            const uint32_t j = __clz( ~( bits6 << 26 ) );   /* leading ones, 6 if all set */
+            br.skip( j + 1 );
+            if ( j >= groupCount ) FAIL( ST_SELECTOR_UNARY );
+            const uint32_t shj = 4 * j;
+            const uint32_t val = ( mtfsel >> shj ) & 0xFu;
+            const uint32_t low = mtfsel & ( ( 1u << shj ) - 1u );
+            const uint32_t highMask = ~( ( 16u << shj ) - 1u );
+            mtfsel = ( mtfsel & highMask ) | ( low << 4 ) | val;
+            packed |= val << ( 8 * ( i & 3 ) );
+            if ( ( i & 3 ) == 3 || i + 1 == nSel ) {
+                if ( lane == 0 ) *reinterpret_cast<uint32_t*>( sel + ( i & ~3u ) ) = packed;
+                packed = 0;
+            }
+        }
+    }
+
+    /* ---- Block::readTrees, bzip2.hpp:644-685, and the canonical tables ---- */
+    {
+        const uint32_t symCount = symbolCount + 2;
+        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            uint32_t hh = br.read( 5 );
+            if ( br.eof ) FAIL( ST_EOF );
+            for ( uint32_t s = 0; s < symCount; ++s ) {
+                for ( ;; ) {
+                    if ( hh - 1u > 19u ) FAIL( ST_CODE_LENGTH );
+                    br.refill();
+                    const uint32_t b2 = br.peek( 2 );
+                    if ( b2 < 2 ) {
+                        if ( br.pos + 1 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+                        br.skip( 1 );
+                        break;
+                    }
+                    if ( br.pos + 2 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+                    hh += b2 == 2 ? 1u : 0xFFFFFFFFu;
+                    br.skip( 2 );
+                }
+                if ( lane == 0 ) sh.lens[t][s] = (uint8_t)hh;
+            }
+        }
+        __syncthreads();
+
+        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            uint32_t c = 0;
+            if ( lane >= 1 && lane <= 20 ) {
+                for ( uint32_t s = 0; s < symCount; ++s ) c += sh.lens[t][s] == lane;
+            }
+            if ( lane < 24 ) sh.count[t][lane] = c;
+            __syncthreads();
+            uint32_t minLen = 0, maxLen = 0;
+            for ( uint32_t l = 1; l <= 20; ++l ) {
+                if ( sh.count[t][l] != 0 ) {
+                    if ( minLen == 0 ) minLen = l;
+                    maxLen = l;
+                }
+            }
+            {
+                uint32_t unused = 1u << minLen;
+                bool bad = false;
+                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
+                    const uint32_t f = sh.count[t][l];
+                    if ( f > unused ) { bad = true; break; }
+                    unused = ( unused - f ) * 2u;
+                }
+                if ( bad ) FAIL( ST_HUFFMAN_LENGTHS );
+            }
+            if ( lane == 0 ) {
+                uint32_t minCode = 0, sum = 0;
+                for ( uint32_t l = 0; l < 24; ++l ) { sh.first[t][l] = 0; sh.offs[t][l] = 0; }
+                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
+                    minCode = ( minCode + ( l > minLen ? sh.count[t][l - 1] : 0u ) ) << 1;
+                    if ( l == minLen ) minCode = 0;
+                    sh.first[t][l] = minCode;
+                    sh.offs[t][l] = sum;
+                    sh.running[l] = sum;
+                    sum += sh.count[t][l];
+                }
+                sh.minmax[t] = minLen | ( maxLen << 8 );
+            }
+            __syncthreads();
+            for ( uint32_t base = 0; base < symCount; base += 64 ) {
+                const uint32_t s = base + lane;
+                const bool valid = s < symCount;
+                const uint32_t len = valid ? sh.lens[t][s] : 0u;
+                const uint64_t same = match_any( len, 5, valid );
+                const uint32_t rank = popc_below( same, lane );
+                uint32_t basePos = 0;
+                if ( valid ) basePos = sh.running[len];
+                if ( valid ) sh.perm[t][basePos + rank] = (uint16_t)s;
+                __syncthreads();
+                if ( valid && rank == 0 ) sh.running[len] = basePos + (uint32_t)__popcll( same );
+                __syncthreads();
+            }
+            /* single-symbol half */
+            const uint32_t lutMax = maxLen < (uint32_t)LUT_BITS ? maxLen : (uint32_t)LUT_BITS;
+            for ( uint32_t e = lane; e < ( 1u << LUT_BITS ); e += 64 ) {
+                uint32_t val = 0;
+                for ( uint32_t l = minLen; l <= lutMax; ++l ) {
+                    const uint32_t code = e >> ( LUT_BITS - l );
+                    const uint32_t d = code - sh.first[t][l];
+                    if ( d < sh.count[t][l] ) {
+                        val = l | ( (uint32_t)sh.perm[t][sh.offs[t][l] + d] << 5 );
+                        break;
+                    }
+                }
+                sh.lut[t][e] = val;
+            }
+            __syncthreads();
+            /* multi-symbol half: all codes that lie completely inside the LUT_BITS index bits */
+            for ( uint32_t e = lane; e < ( 1u << LUT_BITS ); e += 64 ) {
+                uint32_t p = 0, mask = 0;
+                while ( p < (uint32_t)LUT_BITS ) {
+                    const uint32_t idx = ( e << p ) & ( ( 1u << LUT_BITS ) - 1u );
+                    const uint32_t len = sh.lut[t][idx] & 31u;
+                    if ( len == 0 || p + len > (uint32_t)LUT_BITS ) break;
+                    mask |= 1u << p;
+                    p += len;
+                }
+                const uint32_t multi = mask | ( p << 10 );
+                /* all single halves are final before any entry is rewritten (barrier above); OR keeps the low half */
+                atomicOr( &sh.lut[t][e], multi << 16 );
+            }
+            __syncthreads();
+        }
+    }
+    active = 1;
+
+    /* ---- symbol loop of Block::readBlockData, bzip2.hpp:709-723, window-parallel ---- */
+    {
+        uint64_t pos = br.pos;
+        const uint64_t sizeBits = br.size_bits;
+        const uint32_t eob = symbolCount + 1;
+        uint32_t groupLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
+        bool finished = false;
+        for ( ;; ) {
+            if ( groupLeft == 0 ) {
+                if ( selIdx >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
+                tcur = sfl( (uint32_t)sel[selIdx] );
+                ++selIdx;
+                groupLeft = 50;
+                tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
+            }
+            /* 128-bit window starting at the dword that contains `pos` (the input copy is zero padded) */
+            const uint64_t w0 = pos >> 5;
+            const uint32_t s0 = __builtin_bswap32( sfl( in_words[w0] ) );
+            const uint32_t s1 = __builtin_bswap32( sfl( in_words[w0 + 1] ) );
+            const uint32_t s2 = __builtin_bswap32( sfl( in_words[w0 + 2] ) );
+            const uint32_t s3 = __builtin_bswap32( sfl( in_words[w0 + 3] ) );
+            const uint32_t t = (uint32_t)( pos & 31 ) + lane;
+            const uint32_t wi = t >> 5, shv = t & 31;
+            const uint32_t hi = wi == 0 ? s0 : ( wi == 1 ? s1 : s2 );
+            const uint32_t lo = wi == 0 ? s1 : ( wi == 1 ? s2 : s3 );
+            const uint32_t bits32 = shv == 0 ? hi : ( ( hi << shv ) | ( lo >> ( 32 - shv ) ) );
+            const uint32_t E = sh.lut[tcur][bits32 >> ( 32 - LUT_BITS )];
+            const uint32_t Mv = E >> 16;
+
+            /* follow the code chain on the scalar unit */
+            uint32_t cur = 0;
+            uint64_t mask = 0;
+            bool longCode = false;
+            do {
+                const uint32_t e = __builtin_amdgcn_readlane( Mv, cur );
+                const uint32_t adv = e >> 10;
+                if ( adv == 0 ) { longCode = true; break; }
+                mask |= (uint64_t)( e & 0x3FFu ) << cur;
+                cur += adv;
+            } while ( cur < 54 );
+
+            uint32_t nSyms = (uint32_t)__popcll( mask );
+            uint32_t consumed = cur;
+            const uint32_t myLen = E & 31u;
+            const uint32_t mySym = ( E & 0xFFFFu ) >> 5;
+            /* group boundary inside the window: keep the first groupLeft symbols, the rest use the next table */
+            if ( nSyms > groupLeft ) {
+                const bool isStart = ( mask >> lane ) & 1ull;
+                const uint64_t cutAt = __ballot( isStart && popc_below( mask, lane ) == groupLeft );
+                const uint32_t pcut = (uint32_t)__builtin_ctzll( cutAt );
+                mask &= ( 1ull << pcut ) - 1ull;
+                consumed = pcut;
+                nSyms = groupLeft;
+                longCode = false;
+            }
+            /* end-of-block symbol */
+            {
+                const bool onChain = ( mask >> lane ) & 1ull;
+                const uint64_t eobMask = __ballot( onChain && mySym == eob );
+                if ( eobMask != 0 ) {
+                    const uint32_t pe = (uint32_t)__builtin_ctzll( eobMask );
+                    mask &= ( 1ull << pe ) - 1ull;     /* EOB itself is not stored */
+                    nSyms = (uint32_t)__popcll( mask );
+                    consumed = pe + ( __builtin_amdgcn_readlane( E, pe ) & 31u );
+                    finished = true;
+                    longCode = false;
+                }
+            }
+            /* a code must end inside the input (the bit reader throws otherwise) */
+            if ( pos + consumed > sizeBits ) {
+                const bool onChain = ( mask >> lane ) & 1ull;
+                const uint64_t viol = __ballot( onChain && pos + lane + myLen > sizeBits );
+                if ( viol != 0 || finished ) {
+                    const uint32_t pv = viol != 0 ? (uint32_t)__builtin_ctzll( viol ) : 64u;
+                    if ( pv < 64 ) {
+                        mask &= ( 1ull << pv ) - 1ull;
+                        nSyms = (uint32_t)__popcll( mask );
+                    }
+                    status = ST_EOF;
+                    finished = false;
+                    longCode = false;
+                }
+            }
+            /* store the symbols of this window */
+            {
+                const bool onChain = ( mask >> lane ) & 1ull;
+                if ( cnt + nSyms > SYM_CAP ) { status = ST_DATA_OVERFLOW; break; }
+                if ( onChain ) symOut[cnt + popc_below( mask, lane )] = (uint16_t)mySym;
+                cnt += nSyms;
+                nsym += nSyms;
+                groupLeft -= nSyms;
+            }
+            if ( status != ST_OK ) break;
+            pos += consumed;
+            if ( finished ) { ++nsym; break; }
+
+            if ( longCode && groupLeft > 0 ) {
+                /* decodeLong, HuffmanCodingShortBitsCached.hpp:117-150, for the one code at `pos` */
+                const uint32_t b32 = __builtin_amdgcn_readlane( bits32, cur );
+                uint32_t len = 0, sym = 0;
+                for ( uint32_t l = LUT_BITS + 1; l <= tMaxLen; ++l ) {
+                    const uint32_t code = b32 >> ( 32 - l );
+                    const uint32_t d = code - sfl( sh.first[tcur][l] );
+                    if ( d < sfl( sh.count[tcur][l] ) ) {
+                        sym = sfl( (uint32_t)sh.perm[tcur][sfl( sh.offs[tcur][l] ) + d] );
+                        len = l;
+                        break;
+                    }
+                }
+                if ( len == 0 ) {
+                    status = ( pos + tMaxLen > sizeBits ) ? ST_EOF : ST_INVALID_CODE;
+                    break;
+                }
+                if ( pos + len > sizeBits ) { status = ST_EOF; break; }
+                pos += len;
+                ++nsym;
+                --groupLeft;
+                if ( sym == eob ) { finished = true; break; }
+                if ( cnt + 1 > SYM_CAP ) { status = ST_DATA_OVERFLOW; break; }
+                if ( lane == 0 ) symOut[cnt] = (uint16_t)sym;
+                ++cnt;
+            }
+        }
+        encSize = pos - start;
+    }
+
+finish:
+#undef FAIL
+    if ( lane == 0 ) {
+        BlockMeta mt;
+        mt.enc_off = start;
+        mt.enc_size = encSize;
+        mt.decoded_size = 0;
+        mt.out_off = 0;
+        mt.header_crc = headerCrc;
+        mt.computed_crc = 0xFFFFFFFFu;
+        mt.n = 0;
+        mt.orig_ptr = origPtr;
+        mt.nsym = nsym;
+        mt.is_eos = isEos;
+        mt.is_eof = isEof;
+        mt.status = status;
+        mt.seg_stride = MIN_SEG_STRIDE;
+        mt.nseg = 0;
+        mt.walk_ok = 0;
+        mt.cycle_len = 0;
+        meta[b] = mt;
+        HuffMeta hm;
+        hm.n_stored = cnt;
+        hm.symbol_count = symbolCount;
+        hm.status = status;
+        hm.active = active;
+        hmeta[b] = hm;
+    }
+}
+
+/* ============================================================================================================= */
+
+/** Move entry `ii` of this lane's list to the front; returns the entry.  Dword k of lane t is lists[k * MTF_THREADS + t]. */
+__device__ __forceinline__ uint32_t
+mtf_lane_move( uint32_t* lists, uint32_t t, uint32_t ii )
+{
+    const uint32_t q = ii >> 2, r = ii & 3;
+    const uint32_t dq = lists[q * MTF_THREADS + t];
+    const uint32_t x = ( dq >> ( 8 * r ) ) & 0xFFu;
+    uint32_t carry = x;
+    for ( uint32_t k = 0; k < q; ++k ) {
+        const uint32_t old = lists[k * MTF_THREADS + t];
+        lists[k * MTF_THREADS + t] = ( old << 8 ) | carry;
+        carry = old >> 24;
+    }
+    const uint32_t lowMask = r == 3 ? 0xFFFFFFFFu : ( ( 1u << ( 8 * ( r + 1 ) ) ) - 1u );
+    lists[q * MTF_THREADS + t] = ( ( ( dq << 8 ) | carry ) & lowMask ) | ( dq & ~lowMask );
+    return x;
+}
+
+__global__ __launch_bounds__( MTF_THREADS ) void
+k_mtf( BlockMeta* __restrict__       meta,
+       const HuffMeta* __restrict__  hmeta,
+       const uint16_t* __restrict__  sym_buf,
+       const uint8_t* __restrict__   stb_buf,
+       uint8_t* __restrict__         l_buf )
+{
+    __shared__ uint32_t lists[64 * MTF_THREADS];   /* 32 KiB */
+    __shared__ uint8_t cur[256];
+    __shared__ uint32_t starts[MTF_THREADS + 1];
+    __shared__ unsigned long long waveTotals[MTF_THREADS / 64];
+    __shared__ uint32_t firstError;
+
+    const uint32_t b = blockIdx.x;
+    const HuffMeta hm = hmeta[b];
+    if ( !hm.active ) return;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t n = hm.n_stored;
+    const uint16_t* const sym = sym_buf + (size_t)b * SYM_STRIDE;
+    uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
+
+    /* chunk boundaries: never inside a RUNA/RUNB digit sequence */
+    const uint32_t S = ( n + MTF_THREADS - 1 ) / MTF_THREADS;
+    uint32_t begin = t * S < n ? t * S : n;
+    while ( begin < n && begin > 0 && sym[begin] <= 1 && sym[begin - 1] <= 1 ) ++begin;
+    starts[t] = begin;
+    if ( t == 0 ) { starts[MTF_THREADS] = n; firstError = 0xFFFFFFFFu; }
+    cur[t] = stb_buf[(size_t)b * 256 + t];
+    cur[t + 128] = stb_buf[(size_t)b * 256 + t + 128];
+    for ( uint32_t k = 0; k < 64; ++k ) {
+        lists[k * MTF_THREADS + t] = ( 4 * k ) | ( ( 4 * k + 1 ) << 8 ) | ( ( 4 * k + 2 ) << 16 ) | ( ( 4 * k + 3 ) << 24 );
+    }
+    __syncthreads();
+    const uint32_t end = starts[t + 1];
+
+    /* ---- pass A: chunk permutation and output size ---- */
+    unsigned long long count = 0;
+    {
+        uint32_t runPos = 0, hh = 0;
+        for ( uint32_t i = begin; i < end; ++i ) {
+            const uint32_t s = sym[i];
+            if ( s <= 1 ) {
+                if ( runPos == 0 ) { runPos = 1; hh = 0; }
+                hh += runPos << s;
+                runPos <<= 1;
+            } else {
+                if ( runPos != 0 ) { count += hh; runPos = 0; }
+                mtf_lane_move( lists, t, s - 1 );
+                ++count;
+            }
+        }
+        if ( runPos != 0 ) count += hh;
+    }
+    /* exclusive prefix sum of the chunk sizes */
+    unsigned long long incl = count;
+    for ( int d = 1; d < 64; d <<= 1 ) {
+        const unsigned long long o = __shfl_up( incl, d );
+        if ( (int)lane >= d ) incl += o;
+    }
+    if ( lane == 63 ) waveTotals[wave] = incl;
+    __syncthreads();
+    unsigned long long prefix = incl - count, total = 0;
+    for ( uint32_t w = 0; w < MTF_THREADS / 64; ++w ) {
+        if ( w < wave ) prefix += waveTotals[w];
+        total += waveTotals[w];
+    }
+
+    /* ---- compose the chunk permutations in order: slot c receives the list valid at the start of chunk c ---- */
+    for ( uint32_t c = 0; c < MTF_THREADS; ++c ) {
+        const uint32_t j0 = t, j1 = t + 128;
+        const uint32_t p0 = ( lists[( j0 >> 2 ) * MTF_THREADS + c] >> ( 8 * ( j0 & 3 ) ) ) & 0xFFu;
+        const uint32_t p1 = ( lists[( j1 >> 2 ) * MTF_THREADS + c] >> ( 8 * ( j1 & 3 ) ) ) & 0xFFu;
+        const uint8_t v0 = cur[p0], v1 = cur[p1];
+        const uint8_t o0 = cur[j0], o1 = cur[j1];
+        __syncthreads();
+        reinterpret_cast<uint8_t*>( &lists[( j0 >> 2 ) * MTF_THREADS + c] )[j0 & 3] = o0;
+        reinterpret_cast<uint8_t*>( &lists[( j1 >> 2 ) * MTF_THREADS + c] )[j1 & 3] = o1;
+        cur[j0] = v0;
+        cur[j1] = v1;
+        __syncthreads();
+    }
+
+    /* ---- pass B: replay with the true start list, write the L column ---- */
+    {
+        unsigned long long o = prefix;
+        uint32_t runPos = 0, hh = 0;
+        uint32_t err = 0;
+        for ( uint32_t i = begin; i < end && err == 0; ++i ) {
+            const uint32_t s = sym[i];
+            if ( s <= 1 ) {
+                if ( runPos == 0 ) { runPos = 1; hh = 0; }
+                hh += runPos << s;
+                runPos <<= 1;
+                continue;
+            }
+            if ( runPos != 0 ) {
+                runPos = 0;
+                if ( o + hh > MAX_N ) { err = ST_RUN_OVERFLOW; break; }
+                const uint8_t uc = (uint8_t)( lists[t] & 0xFFu );
+                for ( uint32_t z = 0; z < hh; ++z ) L[o + z] = uc;
+                o += hh;
+            }
+            if ( o >= MAX_N ) { err = ST_DATA_OVERFLOW; break; }
+            L[o++] = (uint8_t)mtf_lane_move( lists, t, s - 1 );
+        }
+        /* a run that is still open where the Huffman stage FAILED is never flushed by the reference */
+        if ( err == 0 && runPos != 0 && ( end < n || hm.status == ST_OK ) ) {
+            if ( o + hh > MAX_N ) {
+                err = ST_RUN_OVERFLOW;
+            } else {
+                const uint8_t uc = (uint8_t)( lists[t] & 0xFFu );
+                for ( uint32_t z = 0; z < hh; ++z ) L[o + z] = uc;
+            }
+        }
+        if ( err != 0 ) atomicMin( &firstError, ( t << 8 ) | err );
+    }
+    __syncthreads();
+    if ( t == 0 ) {
+        /* The first failure in symbol order wins, as in the sequential reference: an overflow found here lies before
+         * the point where the Huffman stage stopped. */
+        int32_t status = hm.status;
+        if ( firstError != 0xFFFFFFFFu ) status = (int32_t)( firstError & 0xFFu );
+        const uint32_t N = status == ST_OK ? (uint32_t)total : 0u;
+        const uint32_t origPtr = meta[b].orig_ptr;
+        if ( status == ST_OK && origPtr >= N ) status = ST_ORIGPTR_DATA;
+        meta[b].n = status == ST_OK || status == ST_ORIGPTR_DATA ? (uint32_t)total : 0u;
+        meta[b].status = status;
+        uint32_t stride = ( N + KMAX - 1 ) / KMAX;
+        if ( stride < MIN_SEG_STRIDE ) stride = MIN_SEG_STRIDE;
+        const uint32_t k0 = ( N + stride - 1 ) / stride;
+        meta[b].seg_stride = stride;
+        meta[b].nseg = k0 + ( ( N > 0 && origPtr % stride != 0 ) ? 1u : 0u );
+        meta[b].walk_ok = ( status == ST_OK && N > 0 ) ? 1u : 0u;
+    }
+}
+}  // namespace bz2gpu
