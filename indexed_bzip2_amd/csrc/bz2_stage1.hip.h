@@ -24,7 +24,17 @@ namespace bz2gpu
 {
 constexpr uint32_t SYM_STRIDE = 900224;       /* u16 symbols per block (n_sym <= N + 1 <= 900001 for valid blocks) */
 constexpr uint32_t SYM_CAP = 900096;
-constexpr uint32_t MTF_THREADS = 128;
+constexpr uint32_t MTF_THREADS = 128;      /* lanes (= chunks) per block in k_mtf */
+constexpr uint32_t MTF_BLOCKS_PER_WG = 2;  /* 256-thread workgroups: all four SIMDs of a CU get a wave */
+constexpr uint32_t HUFF_WAVES = 1;      /* independent blocks (one per wavefront) per k_huff workgroup */
+
+/** Orders LDS traffic between the lanes of ONE wavefront (no s_barrier: the waves of a k_huff workgroup are independent). */
+__device__ __forceinline__ void
+wave_sync()
+{
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    __builtin_amdgcn_wave_barrier();
+}
 
 /** Per-block hand-off between k_huff and k_mtf. */
 struct HuffMeta
@@ -50,7 +60,7 @@ struct HuffShared
     uint32_t minmax[6];
 };
 
-__global__ __launch_bounds__( 64 ) void
+__global__ __launch_bounds__( 64 * HUFF_WAVES ) void
 k_huff( const uint32_t* __restrict__ in_words,
         uint64_t                     in_size_bytes,
         const uint64_t* __restrict__ offsets,
@@ -58,11 +68,16 @@ k_huff( const uint32_t* __restrict__ in_words,
         HuffMeta* __restrict__       hmeta,
         uint8_t*                     sel_buf,
         uint16_t* __restrict__       sym_buf,
-        uint8_t* __restrict__        stb_buf )
+        uint8_t* __restrict__        stb_buf,
+        uint32_t                     n_blocks )
 {
-    __shared__ HuffShared sh;
-    const uint32_t b = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
+    /* HUFF_WAVES independent blocks per workgroup, one per wavefront: a 256-thread workgroup is guaranteed to put its
+     * four waves on the four SIMDs of the CU, which single-wave workgroups are not (they were observed to pile up). */
+    __shared__ HuffShared shAll[HUFF_WAVES];
+    HuffShared& sh = shAll[threadIdx.x >> 6];
+    const uint32_t b = blockIdx.x * HUFF_WAVES + ( threadIdx.x >> 6 );
+    if ( b >= n_blocks ) return;
+    const uint32_t lane = threadIdx.x & 63;
     uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
     uint16_t* const symOut = sym_buf + (size_t)b * SYM_STRIDE;
 
@@ -121,7 +136,7 @@ k_huff( const uint32_t* __restrict__ in_words,
             }
             if ( lane == 0 ) sh.bitmap[i] = (uint16_t)bm;
         }
-        __syncthreads();
+        wave_sync();
         uint32_t total = 0;
         for ( int g = 0; g < 16; ++g ) total += __popc( sh.bitmap[g] );
         symbolCount = total;
@@ -135,7 +150,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 sh.sym_to_byte[rank] = (uint8_t)v;
             }
         }
-        __syncthreads();
+        wave_sync();
         if ( br.eof ) FAIL( ST_EOF );
         reinterpret_cast<uint32_t*>( stb_buf + (size_t)b * 256 )[lane] =
             reinterpret_cast<const uint32_t*>( sh.sym_to_byte )[lane];
@@ -197,7 +212,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 if ( lane == 0 ) sh.lens[t][s] = (uint8_t)hh;
             }
         }
-        __syncthreads();
+        wave_sync();
 
         for ( uint32_t t = 0; t < groupCount; ++t ) {
             uint32_t c = 0;
@@ -205,7 +220,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 for ( uint32_t s = 0; s < symCount; ++s ) c += sh.lens[t][s] == lane;
             }
             if ( lane < 24 ) sh.count[t][lane] = c;
-            __syncthreads();
+            wave_sync();
             uint32_t minLen = 0, maxLen = 0;
             for ( uint32_t l = 1; l <= 20; ++l ) {
                 if ( sh.count[t][l] != 0 ) {
@@ -236,7 +251,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 }
                 sh.minmax[t] = minLen | ( maxLen << 8 );
             }
-            __syncthreads();
+            wave_sync();
             for ( uint32_t base = 0; base < symCount; base += 64 ) {
                 const uint32_t s = base + lane;
                 const bool valid = s < symCount;
@@ -246,9 +261,9 @@ k_huff( const uint32_t* __restrict__ in_words,
                 uint32_t basePos = 0;
                 if ( valid ) basePos = sh.running[len];
                 if ( valid ) sh.perm[t][basePos + rank] = (uint16_t)s;
-                __syncthreads();
+                wave_sync();
                 if ( valid && rank == 0 ) sh.running[len] = basePos + (uint32_t)__popcll( same );
-                __syncthreads();
+                wave_sync();
             }
             /* single-symbol half */
             const uint32_t lutMax = maxLen < (uint32_t)LUT_BITS ? maxLen : (uint32_t)LUT_BITS;
@@ -264,7 +279,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 }
                 sh.lut[t][e] = val;
             }
-            __syncthreads();
+            wave_sync();
             /* multi-symbol half: all codes that lie completely inside the LUT_BITS index bits */
             for ( uint32_t e = lane; e < ( 1u << LUT_BITS ); e += 64 ) {
                 uint32_t p = 0, mask = 0;
@@ -279,7 +294,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 /* all single halves are final before any entry is rewritten (barrier above); OR keeps the low half */
                 atomicOr( &sh.lut[t][e], multi << 16 );
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     active = 1;
@@ -290,6 +305,7 @@ k_huff( const uint32_t* __restrict__ in_words,
         const uint64_t sizeBits = br.size_bits;
         const uint32_t eob = symbolCount + 1;
         uint32_t groupLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
+        uint32_t limitV = 0;   /* lane l in (LUT_BITS, 20]: left-aligned (20 bit) end of the length-l code range */
         bool finished = false;
         for ( ;; ) {
             if ( groupLeft == 0 ) {
@@ -298,6 +314,8 @@ k_huff( const uint32_t* __restrict__ in_words,
                 ++selIdx;
                 groupLeft = 50;
                 tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
+                limitV = ( lane > (uint32_t)LUT_BITS && lane <= 20 )
+                         ? ( ( sh.first[tcur][lane] + sh.count[tcur][lane] ) << ( 20 - lane ) ) : 0u;
             }
             /* 128-bit window starting at the dword that contains `pos` (the input copy is zero padded) */
             const uint64_t w0 = pos >> 5;
@@ -313,22 +331,42 @@ k_huff( const uint32_t* __restrict__ in_words,
             const uint32_t E = sh.lut[tcur][bits32 >> ( 32 - LUT_BITS )];
             const uint32_t Mv = E >> 16;
 
-            /* follow the code chain on the scalar unit */
+            /* Follow the code chain on the scalar unit.  A position whose code is longer than LUT_BITS is resolved in
+             * place by comparing its 20-bit window against the per-length code range ends held one per lane
+             * (canonical codes: the first length whose range end exceeds the window is the code length;
+             * = decodeLong, HuffmanCodingShortBitsCached.hpp:117-150). */
             uint32_t cur = 0;
             uint64_t mask = 0;
-            bool longCode = false;
+            uint32_t lenOv = 0;     /* per lane: length of a long code that starts here and is on the chain */
+            bool invalid = false;
             do {
                 const uint32_t e = __builtin_amdgcn_readlane( Mv, cur );
                 const uint32_t adv = e >> 10;
-                if ( adv == 0 ) { longCode = true; break; }
-                mask |= (uint64_t)( e & 0x3FFu ) << cur;
-                cur += adv;
+                if ( adv != 0 ) {
+                    mask |= (uint64_t)( e & 0x3FFu ) << cur;
+                    cur += adv;
+                } else {
+                    const uint32_t v20 = (uint32_t)__builtin_amdgcn_readlane( bits32, cur ) >> 12;   /* readlane returns int */
+                    const uint64_t fits = __ballot( v20 < limitV );
+                    if ( fits == 0 ) { invalid = true; break; }
+                    const uint32_t l = (uint32_t)__builtin_ctzll( fits );
+                    lenOv = lane == cur ? l : lenOv;
+                    mask |= 1ull << cur;
+                    cur += l;
+                }
             } while ( cur < 54 );
 
             uint32_t nSyms = (uint32_t)__popcll( mask );
             uint32_t consumed = cur;
-            const uint32_t myLen = E & 31u;
-            const uint32_t mySym = ( E & 0xFFFFu ) >> 5;
+            uint32_t myLen = E & 31u;
+            uint32_t mySym = ( E & 0xFFFFu ) >> 5;
+            if ( __ballot( lenOv != 0 ) != 0 ) {
+                if ( lenOv != 0 ) {
+                    const uint32_t code = bits32 >> ( 32 - lenOv );
+                    mySym = sh.perm[tcur][sh.offs[tcur][lenOv] + code - sh.first[tcur][lenOv]];
+                    myLen = lenOv;
+                }
+            }
             /* group boundary inside the window: keep the first groupLeft symbols, the rest use the next table */
             if ( nSyms > groupLeft ) {
                 const bool isStart = ( mask >> lane ) & 1ull;
@@ -337,7 +375,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                 mask &= ( 1ull << pcut ) - 1ull;
                 consumed = pcut;
                 nSyms = groupLeft;
-                longCode = false;
+                invalid = false;
             }
             /* end-of-block symbol */
             {
@@ -347,9 +385,9 @@ k_huff( const uint32_t* __restrict__ in_words,
                     const uint32_t pe = (uint32_t)__builtin_ctzll( eobMask );
                     mask &= ( 1ull << pe ) - 1ull;     /* EOB itself is not stored */
                     nSyms = (uint32_t)__popcll( mask );
-                    consumed = pe + ( __builtin_amdgcn_readlane( E, pe ) & 31u );
+                    consumed = pe + __builtin_amdgcn_readlane( myLen, pe );
                     finished = true;
-                    longCode = false;
+                    invalid = false;
                 }
             }
             /* a code must end inside the input (the bit reader throws otherwise) */
@@ -364,7 +402,7 @@ k_huff( const uint32_t* __restrict__ in_words,
                     }
                     status = ST_EOF;
                     finished = false;
-                    longCode = false;
+                    invalid = false;
                 }
             }
             /* store the symbols of this window */
@@ -379,32 +417,11 @@ k_huff( const uint32_t* __restrict__ in_words,
             if ( status != ST_OK ) break;
             pos += consumed;
             if ( finished ) { ++nsym; break; }
-
-            if ( longCode && groupLeft > 0 ) {
-                /* decodeLong, HuffmanCodingShortBitsCached.hpp:117-150, for the one code at `pos` */
-                const uint32_t b32 = __builtin_amdgcn_readlane( bits32, cur );
-                uint32_t len = 0, sym = 0;
-                for ( uint32_t l = LUT_BITS + 1; l <= tMaxLen; ++l ) {
-                    const uint32_t code = b32 >> ( 32 - l );
-                    const uint32_t d = code - sfl( sh.first[tcur][l] );
-                    if ( d < sfl( sh.count[tcur][l] ) ) {
-                        sym = sfl( (uint32_t)sh.perm[tcur][sfl( sh.offs[tcur][l] ) + d] );
-                        len = l;
-                        break;
-                    }
-                }
-                if ( len == 0 ) {
-                    status = ( pos + tMaxLen > sizeBits ) ? ST_EOF : ST_INVALID_CODE;
-                    break;
-                }
-                if ( pos + len > sizeBits ) { status = ST_EOF; break; }
-                pos += len;
-                ++nsym;
-                --groupLeft;
-                if ( sym == eob ) { finished = true; break; }
-                if ( cnt + 1 > SYM_CAP ) { status = ST_DATA_OVERFLOW; break; }
-                if ( lane == 0 ) symOut[cnt] = (uint16_t)sym;
-                ++cnt;
+            if ( invalid ) {
+                /* no code of any length matches at `pos`: the reference runs out of bits first if fewer than the
+                 * longest code remain (oracle: huff_decode) */
+                status = ( pos + tMaxLen > sizeBits ) ? ST_EOF : ST_INVALID_CODE;
+                break;
             }
         }
         encSize = pos - start;
@@ -460,23 +477,31 @@ mtf_lane_move( uint32_t* lists, uint32_t t, uint32_t ii )
     return x;
 }
 
-__global__ __launch_bounds__( MTF_THREADS ) void
+__global__ __launch_bounds__( MTF_THREADS * MTF_BLOCKS_PER_WG ) void
 k_mtf( BlockMeta* __restrict__       meta,
        const HuffMeta* __restrict__  hmeta,
        const uint16_t* __restrict__  sym_buf,
        const uint8_t* __restrict__   stb_buf,
-       uint8_t* __restrict__         l_buf )
+       uint8_t* __restrict__         l_buf,
+       uint32_t                      n_blocks )
 {
-    __shared__ uint32_t lists[64 * MTF_THREADS];   /* 32 KiB */
-    __shared__ uint8_t cur[256];
-    __shared__ uint32_t starts[MTF_THREADS + 1];
-    __shared__ unsigned long long waveTotals[MTF_THREADS / 64];
-    __shared__ uint32_t firstError;
+    __shared__ uint32_t listsAll[MTF_BLOCKS_PER_WG][64 * MTF_THREADS];   /* 32 KiB per block */
+    __shared__ uint8_t curAll[MTF_BLOCKS_PER_WG][256];
+    __shared__ uint32_t startsAll[MTF_BLOCKS_PER_WG][MTF_THREADS + 1];
+    __shared__ unsigned long long waveTotalsAll[MTF_BLOCKS_PER_WG][MTF_THREADS / 64];
+    __shared__ uint32_t firstErrorAll[MTF_BLOCKS_PER_WG];
 
-    const uint32_t b = blockIdx.x;
+    const uint32_t half = threadIdx.x / MTF_THREADS;
+    uint32_t* const lists = listsAll[half];
+    uint8_t* const cur = curAll[half];
+    uint32_t* const starts = startsAll[half];
+    unsigned long long* const waveTotals = waveTotalsAll[half];
+    uint32_t& firstError = firstErrorAll[half];
+    const uint32_t b = blockIdx.x * MTF_BLOCKS_PER_WG + half;
+    if ( b >= n_blocks ) return;   /* exited waves do not take part in later barriers */
     const HuffMeta hm = hmeta[b];
     if ( !hm.active ) return;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t t = threadIdx.x % MTF_THREADS, lane = t & 63, wave = t >> 6;
     const uint32_t n = hm.n_stored;
     const uint16_t* const sym = sym_buf + (size_t)b * SYM_STRIDE;
     uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
