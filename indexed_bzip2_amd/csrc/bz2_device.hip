@@ -144,7 +144,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     if ( cap > nBlocks && (uint64_t)cap * TAB_STRIDE * 4 > ( 64ull << 30 ) ) cap = nBlocks;  /* keep large batches tight */
     HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dMeta, (size_t)cap * sizeof( BlockMeta ) ) );
-    HIP_TRY( c, hipMalloc( &c->dSel, (size_t)cap * SEL_STRIDE ) );
+    HIP_TRY( c, hipMalloc( &c->dSel, (size_t)cap * SEL_STRIDE + 256 ) );
     HIP_TRY( c, hipMalloc( &c->dSym, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dStb, (size_t)cap * 256 ) );
     HIP_TRY( c, hipMalloc( &c->dHmeta, (size_t)cap * sizeof( HuffMeta ) ) );
@@ -329,6 +329,8 @@ mi355x_bz2_set_input_host( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t siz
     if ( size > 0 ) {
         HIP_TRY( c, hipMemcpyAsync( c->dInOwned, bytes, size, hipMemcpyHostToDevice, c->stream ) );
     }
+    hipLaunchKernelGGL( k_bswap32, dim3( 2048 ), dim3( 256 ), 0, c->stream,
+                        reinterpret_cast<uint32_t*>( c->dInOwned ), padded / 4 );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     c->dIn = c->dInOwned;
     c->inSize = size;
@@ -357,6 +359,8 @@ mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_
     if ( size > 0 ) {
         HIP_TRY( c, hipMemcpyAsync( c->dInOwned, deviceBytes, size, hipMemcpyDeviceToDevice, c->stream ) );
     }
+    hipLaunchKernelGGL( k_bswap32, dim3( 2048 ), dim3( 256 ), 0, c->stream,
+                        reinterpret_cast<uint32_t*>( c->dInOwned ), padded / 4 );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     c->dIn = c->dInOwned;
     c->inSize = size;

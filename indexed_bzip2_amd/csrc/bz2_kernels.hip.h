@@ -31,7 +31,7 @@ constexpr uint32_t TAB_STRIDE = 1u << 20;     /* u32 entries per block: every 20
 constexpr uint32_t KMAX = 8192;               /* max regular walk segments per block */
 constexpr uint32_t SEG_STRIDE = KMAX + 64;
 constexpr uint32_t MIN_SEG_STRIDE = 32;
-constexpr int LUT_BITS = 10;
+constexpr int LUT_BITS = 9;
 constexpr uint32_t MARK = 0x80000000u;
 constexpr uint32_t LF_MASK = 0xFFFFFu;
 constexpr uint32_t INVALID_OFF = 0xFFFFFFFFu;
@@ -103,10 +103,7 @@ struct BitRd
     {
         uint32_t v = 0;
         if ( i < nwords ) {
-            v = __builtin_bswap32( sfl( w[i] ) );
-            if ( i == nwords - 1 ) {
-                v &= tail_mask;
-            }
+            v = sfl( w[i] );   /* the ctx keeps the input as big-endian 32-bit words, zero padded (k_bswap32) */
         }
         return v;
     }
@@ -207,6 +204,19 @@ __device__ __forceinline__ uint32_t
 popc_below( uint64_t mask, uint32_t lane )
 {
     return __popcll( mask & ( ( 1ull << lane ) - 1ull ) );
+}
+
+/** In-place byte swap of the ctx-owned input copy: afterwards a 32-bit load yields 32 stream bits MSB first. */
+__global__ __launch_bounds__( 256 ) void
+k_bswap32( uint32_t* __restrict__ words, uint64_t n_words )
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 4;
+    for ( uint64_t i = ( (uint64_t)blockIdx.x * 256 + threadIdx.x ) * 4; i < n_words; i += stride ) {
+        uint4 v = *reinterpret_cast<const uint4*>( words + i );   /* buffer is padded to a multiple of 256 bytes */
+        v.x = __builtin_bswap32( v.x ); v.y = __builtin_bswap32( v.y );
+        v.z = __builtin_bswap32( v.z ); v.w = __builtin_bswap32( v.w );
+        *reinterpret_cast<uint4*>( words + i ) = v;
+    }
 }
 
 /* =============================================================================================================

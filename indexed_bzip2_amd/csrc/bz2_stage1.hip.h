@@ -74,8 +74,9 @@ k_huff( const uint32_t* __restrict__ in_words,
     /* HUFF_WAVES independent blocks per workgroup, one per wavefront: a 256-thread workgroup is guaranteed to put its
      * four waves on the four SIMDs of the CU, which single-wave workgroups are not (they were observed to pile up). */
     __shared__ HuffShared shAll[HUFF_WAVES];
-    HuffShared& sh = shAll[threadIdx.x >> 6];
-    const uint32_t b = blockIdx.x * HUFF_WAVES + ( threadIdx.x >> 6 );
+    const uint32_t waveInGroup = sfl( threadIdx.x >> 6 );   /* wave-uniform: keeps all decoder state in SGPRs */
+    HuffShared& sh = shAll[waveInGroup];
+    const uint32_t b = blockIdx.x * HUFF_WAVES + waveInGroup;
     if ( b >= n_blocks ) return;
     const uint32_t lane = threadIdx.x & 63;
     uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
@@ -303,31 +304,46 @@ k_huff( const uint32_t* __restrict__ in_words,
     {
         uint64_t pos = br.pos;
         const uint64_t sizeBits = br.size_bits;
+        const uint64_t safeEnd = sizeBits > 256 ? sizeBits - 256 : 0;   /* below this no code can cross the end */
         const uint32_t eob = symbolCount + 1;
         uint32_t groupLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
         uint32_t limitV = 0;   /* lane l in (LUT_BITS, 20]: left-aligned (20 bit) end of the length-l code range */
         bool finished = false;
+
+        /* selectors are fetched 8 at a time, one fetch ahead of their use */
+        const uint64_t* const sel64 = reinterpret_cast<const uint64_t*>( sel );
+        uint64_t selCur = 0;
+        uint64_t selNext = sel64[0];
+
+        /* Each lane keeps the four stream words that start at the word of ITS bit position, loaded one window ahead:
+         * a window advances by at most 64 bits, so the words needed next are among them. */
+        uint64_t myWord = ( pos + lane ) >> 5;
+        uint4 D = *reinterpret_cast<const uint4*>( in_words + myWord );
+
         for ( ;; ) {
             if ( groupLeft == 0 ) {
                 if ( selIdx >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
-                tcur = sfl( (uint32_t)sel[selIdx] );
+                if ( ( selIdx & 7u ) == 0 ) {
+                    const uint64_t fetched = selNext;
+                    selCur = ( (uint64_t)sfl( (uint32_t)( fetched >> 32 ) ) << 32 ) | sfl( (uint32_t)fetched );
+                    selNext = sel64[( selIdx >> 3 ) + 1];
+                }
+                tcur = (uint32_t)( selCur >> ( 8 * ( selIdx & 7u ) ) ) & 0xFFu;
                 ++selIdx;
                 groupLeft = 50;
                 tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
                 limitV = ( lane > (uint32_t)LUT_BITS && lane <= 20 )
                          ? ( ( sh.first[tcur][lane] + sh.count[tcur][lane] ) << ( 20 - lane ) ) : 0u;
             }
-            /* 128-bit window starting at the dword that contains `pos` (the input copy is zero padded) */
-            const uint64_t w0 = pos >> 5;
-            const uint32_t s0 = __builtin_bswap32( sfl( in_words[w0] ) );
-            const uint32_t s1 = __builtin_bswap32( sfl( in_words[w0 + 1] ) );
-            const uint32_t s2 = __builtin_bswap32( sfl( in_words[w0 + 2] ) );
-            const uint32_t s3 = __builtin_bswap32( sfl( in_words[w0 + 3] ) );
-            const uint32_t t = (uint32_t)( pos & 31 ) + lane;
-            const uint32_t wi = t >> 5, shv = t & 31;
-            const uint32_t hi = wi == 0 ? s0 : ( wi == 1 ? s1 : s2 );
-            const uint32_t lo = wi == 0 ? s1 : ( wi == 1 ? s2 : s3 );
-            const uint32_t bits32 = shv == 0 ? hi : ( ( hi << shv ) | ( lo >> ( 32 - shv ) ) );
+            /* my 32 stream bits, from the words fetched during the previous window; then fetch for the next one */
+            const uint64_t newWord = ( pos + lane ) >> 5;
+            const uint32_t dsel = (uint32_t)( newWord - myWord );   /* 0..2 */
+            const uint32_t hi = dsel == 0 ? D.x : ( dsel == 1 ? D.y : D.z );
+            const uint32_t lo = dsel == 0 ? D.y : ( dsel == 1 ? D.z : D.w );
+            myWord = newWord;
+            D = *reinterpret_cast<const uint4*>( in_words + myWord );
+            const uint32_t shv = (uint32_t)( pos + lane ) & 31u;
+            const uint32_t bits32 = (uint32_t)( ( ( ( (uint64_t)hi << 32 ) | lo ) << shv ) >> 32 );
             const uint32_t E = sh.lut[tcur][bits32 >> ( 32 - LUT_BITS )];
             const uint32_t Mv = E >> 16;
 
@@ -338,29 +354,46 @@ k_huff( const uint32_t* __restrict__ in_words,
             uint32_t cur = 0;
             uint64_t mask = 0;
             uint32_t lenOv = 0;     /* per lane: length of a long code that starts here and is on the chain */
-            bool invalid = false;
-            do {
-                const uint32_t e = __builtin_amdgcn_readlane( Mv, cur );
-                const uint32_t adv = e >> 10;
-                if ( adv != 0 ) {
-                    mask |= (uint64_t)( e & 0x3FFu ) << cur;
-                    cur += adv;
-                } else {
-                    const uint32_t v20 = (uint32_t)__builtin_amdgcn_readlane( bits32, cur ) >> 12;   /* readlane returns int */
-                    const uint64_t fits = __ballot( v20 < limitV );
-                    if ( fits == 0 ) { invalid = true; break; }
-                    const uint32_t l = (uint32_t)__builtin_ctzll( fits );
-                    lenOv = lane == cur ? l : lenOv;
-                    mask |= 1ull << cur;
-                    cur += l;
-                }
-            } while ( cur < 54 );
+            bool anyLong = false, invalid = false;
+            for ( ;; ) {
+                /* Hot loop, hand scheduled (9 scalar instructions per step): e = Mv[cur]; adv = e >> 10;
+                 * if adv == 0 leave (long code at cur); mask |= (e & 0x3ff) << cur; cur += adv; repeat while cur < 54.
+                 * s[96:99] are scratch: s96 receives the lane value, s97 is don't-care (masked by the 64-bit and). */
+                uint32_t adv;
+                asm volatile(
+                    "1:\n\t"
+                    "v_readlane_b32 s96, %[M], %[cur]\n\t"
+                    "s_lshr_b32 %[adv], s96, 10\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "s_and_b64 s[98:99], s[96:97], 0x3ff\n\t"
+                    "s_lshl_b64 s[98:99], s[98:99], %[cur]\n\t"
+                    "s_or_b64 %[mask], %[mask], s[98:99]\n\t"
+                    "s_add_u32 %[cur], %[cur], %[adv]\n\t"
+                    "s_cmp_lt_u32 %[cur], 54\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "2:\n\t"
+                    : [cur] "+s"( cur ), [mask] "+s"( mask ), [adv] "=&s"( adv )
+                    : [M] "v"( Mv )
+                    : "scc", "s96", "s97", "s98", "s99" );
+                if ( adv != 0 ) break;   /* cur >= 54 */
+                if ( cur > 44 ) break;   /* a long code here could end past bit 64: leave it to the next window, so that
+                                            a window never advances by more than 64 bits (the prefetched words cover 95) */
+                const uint32_t v20 = (uint32_t)__builtin_amdgcn_readlane( bits32, cur ) >> 12;   /* readlane returns int */
+                const uint64_t fits = __ballot( v20 < limitV );
+                if ( fits == 0 ) { invalid = true; break; }
+                const uint32_t l = (uint32_t)__builtin_ctzll( fits );
+                lenOv = lane == cur ? l : lenOv;
+                anyLong = true;
+                mask |= 1ull << cur;
+                cur += l;
+                if ( cur >= 54 ) break;
+            }
 
             uint32_t nSyms = (uint32_t)__popcll( mask );
             uint32_t consumed = cur;
             uint32_t myLen = E & 31u;
             uint32_t mySym = ( E & 0xFFFFu ) >> 5;
-            if ( __ballot( lenOv != 0 ) != 0 ) {
+            if ( anyLong ) {
                 if ( lenOv != 0 ) {
                     const uint32_t code = bits32 >> ( 32 - lenOv );
                     mySym = sh.perm[tcur][sh.offs[tcur][lenOv] + code - sh.first[tcur][lenOv]];
@@ -369,8 +402,9 @@ k_huff( const uint32_t* __restrict__ in_words,
             }
             /* group boundary inside the window: keep the first groupLeft symbols, the rest use the next table */
             if ( nSyms > groupLeft ) {
-                const bool isStart = ( mask >> lane ) & 1ull;
-                const uint64_t cutAt = __ballot( isStart && popc_below( mask, lane ) == groupLeft );
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ),
+                                                                 __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
+                const uint64_t cutAt = __ballot( __builtin_amdgcn_inverse_ballot_w64( mask ) && rank == groupLeft );
                 const uint32_t pcut = (uint32_t)__builtin_ctzll( cutAt );
                 mask &= ( 1ull << pcut ) - 1ull;
                 consumed = pcut;
@@ -379,25 +413,22 @@ k_huff( const uint32_t* __restrict__ in_words,
             }
             /* end-of-block symbol */
             {
-                const bool onChain = ( mask >> lane ) & 1ull;
-                const uint64_t eobMask = __ballot( onChain && mySym == eob );
+                const uint64_t eobMask = __ballot( mySym == eob ) & mask;
                 if ( eobMask != 0 ) {
                     const uint32_t pe = (uint32_t)__builtin_ctzll( eobMask );
                     mask &= ( 1ull << pe ) - 1ull;     /* EOB itself is not stored */
                     nSyms = (uint32_t)__popcll( mask );
-                    consumed = pe + __builtin_amdgcn_readlane( myLen, pe );
+                    consumed = pe + (uint32_t)__builtin_amdgcn_readlane( myLen, pe );
                     finished = true;
                     invalid = false;
                 }
             }
-            /* a code must end inside the input (the bit reader throws otherwise) */
-            if ( pos + consumed > sizeBits ) {
-                const bool onChain = ( mask >> lane ) & 1ull;
-                const uint64_t viol = __ballot( onChain && pos + lane + myLen > sizeBits );
+            /* a code must end inside the input (the bit reader throws otherwise); only possible near the end */
+            if ( pos > safeEnd && pos + consumed > sizeBits ) {
+                const uint64_t viol = __ballot( pos + lane + myLen > sizeBits ) & mask;
                 if ( viol != 0 || finished ) {
-                    const uint32_t pv = viol != 0 ? (uint32_t)__builtin_ctzll( viol ) : 64u;
-                    if ( pv < 64 ) {
-                        mask &= ( 1ull << pv ) - 1ull;
+                    if ( viol != 0 ) {
+                        mask &= ( 1ull << (uint32_t)__builtin_ctzll( viol ) ) - 1ull;
                         nSyms = (uint32_t)__popcll( mask );
                     }
                     status = ST_EOF;
@@ -406,14 +437,15 @@ k_huff( const uint32_t* __restrict__ in_words,
                 }
             }
             /* store the symbols of this window */
-            {
-                const bool onChain = ( mask >> lane ) & 1ull;
-                if ( cnt + nSyms > SYM_CAP ) { status = ST_DATA_OVERFLOW; break; }
-                if ( onChain ) symOut[cnt + popc_below( mask, lane )] = (uint16_t)mySym;
-                cnt += nSyms;
-                nsym += nSyms;
-                groupLeft -= nSyms;
+            if ( cnt + nSyms > SYM_CAP ) { status = ST_DATA_OVERFLOW; break; }
+            if ( __builtin_amdgcn_inverse_ballot_w64( mask ) ) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ),
+                                                                 __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
+                symOut[cnt + rank] = (uint16_t)mySym;
             }
+            cnt += nSyms;
+            nsym += nSyms;
+            groupLeft -= nSyms;
             if ( status != ST_OK ) break;
             pos += consumed;
             if ( finished ) { ++nsym; break; }

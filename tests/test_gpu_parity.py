@@ -61,6 +61,20 @@ def test_generated(native, oracle, dec, name):
     check_blocks(native, oracle, dec, enc, raw)
 
 
+def test_silesia_style_slice(native, oracle, dec):
+    """24 MB of the benchmark corpus (all segment types: long Huffman codes, high-entropy blocks, long runs) as one
+    stitched single-stream file: every block bit-exact against the oracle, stages included."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import silesia_like, bz2build
+    data = silesia_like.generate(24_000_000, threads=8)
+    enc, nb, offs = bz2build.build(data, 1, piece_size=6_000_000, threads=8, find_magic=native.find_magic)
+    assert nb >= 24
+    check_blocks(native, oracle, dec, enc, data.tobytes())
+    # and the stream CRC stored in the stitched file equals the combination of the block CRCs (bz2build + GPU)
+    assert oracle.decode_file(enc)[0] == 0
+
+
 def test_multistream(native, oracle, dec):
     parts = [datagen.text_like(250_000, 31), datagen.random_bytes(150_000, 32), b"", b"x", datagen.runs(99_999, 33)]
     enc = datagen.multistream(parts, 1)
