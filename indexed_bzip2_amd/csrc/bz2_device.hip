@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -39,6 +40,8 @@ struct mi355x_bz2_ctx
     /* per-block scratch, capacity in blocks */
     uint32_t capacity{ 0 };
     uint64_t* dOffsets{ nullptr };
+    uint32_t* dOrder{ nullptr };
+    uint32_t* hOrder{ nullptr };       /* pinned */
     BlockMeta* dMeta{ nullptr };
     uint8_t* dSel{ nullptr };
     uint16_t* dSym{ nullptr };
@@ -117,6 +120,8 @@ void
 freeScratch( mi355x_bz2_ctx* c )
 {
     (void)hipFree( c->dOffsets ); c->dOffsets = nullptr;
+    (void)hipFree( c->dOrder ); c->dOrder = nullptr;
+    (void)hipHostFree( c->hOrder ); c->hOrder = nullptr;
     (void)hipFree( c->dMeta ); c->dMeta = nullptr;
     (void)hipFree( c->dSel ); c->dSel = nullptr;
     (void)hipFree( c->dSym ); c->dSym = nullptr;
@@ -143,6 +148,8 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     while ( cap < nBlocks ) cap *= 2;
     if ( cap > nBlocks && (uint64_t)cap * TAB_STRIDE * 4 > ( 64ull << 30 ) ) cap = nBlocks;  /* keep large batches tight */
     HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dOrder, (size_t)cap * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipHostMalloc( &c->hOrder, (size_t)cap * sizeof( uint32_t ), hipHostMallocDefault ) );
     HIP_TRY( c, hipMalloc( &c->dMeta, (size_t)cap * sizeof( BlockMeta ) ) );
     HIP_TRY( c, hipMalloc( &c->dSel, (size_t)cap * SEL_STRIDE + 256 ) );
     HIP_TRY( c, hipMalloc( &c->dSym, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) ) );
@@ -390,6 +397,22 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
 
     std::memcpy( c->hOffsets, offsets, (size_t)n * sizeof( uint64_t ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
+    {
+        /* Work order for the latency-bound stage-1 kernels: estimated compressed size (distance to the next requested
+         * offset, or to the end of the input) descending.  Purely a scheduling hint; results are indexed by block. */
+        std::vector<uint32_t> byOffset( n );
+        for ( uint32_t i = 0; i < n; ++i ) byOffset[i] = i;
+        std::sort( byOffset.begin(), byOffset.end(), [&] ( uint32_t a, uint32_t b ) { return offsets[a] < offsets[b]; } );
+        std::vector<uint64_t> cost( n );
+        for ( uint32_t k = 0; k < n; ++k ) {
+            const uint64_t next = k + 1 < n ? offsets[byOffset[k + 1]] : c->inSize * 8;
+            const uint64_t cur = offsets[byOffset[k]];
+            cost[byOffset[k]] = next > cur ? next - cur : 0;
+        }
+        for ( uint32_t i = 0; i < n; ++i ) c->hOrder[i] = i;
+        std::stable_sort( c->hOrder, c->hOrder + n, [&] ( uint32_t a, uint32_t b ) { return cost[a] > cost[b]; } );
+        HIP_TRY( c, hipMemcpyAsync( c->dOrder, c->hOrder, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
+    }
 
     if ( c->useV1Stage1 ) {
         /* fused v1 kernel kept for A/B comparison (MI355X_BZ2_V1_STAGE1=1) */
@@ -400,10 +423,10 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     } else {
         TIMED_LAUNCH( c, 0, k_huff, dim3( ( n + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), 0, c->stream,
                       reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dHmeta, c->dSel,
-                      c->dSym, c->dStb, n );
+                      c->dSym, c->dStb, n, c->dOrder );
         TIMED_LAUNCH( c, 1, k_mtf, dim3( ( n + MTF_BLOCKS_PER_WG - 1 ) / MTF_BLOCKS_PER_WG ),
                       dim3( MTF_THREADS * MTF_BLOCKS_PER_WG ), 0, c->stream,
-                      c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL, n );
+                      c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL, n, c->dOrder );
     }
     TIMED_LAUNCH( c, 2, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
     const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );

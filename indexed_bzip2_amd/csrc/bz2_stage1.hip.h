@@ -69,15 +69,19 @@ k_huff( const uint32_t* __restrict__ in_words,
         uint8_t*                     sel_buf,
         uint16_t* __restrict__       sym_buf,
         uint8_t* __restrict__        stb_buf,
-        uint32_t                     n_blocks )
+        uint32_t                     n_blocks,
+        const uint32_t* __restrict__ order )
 {
     /* HUFF_WAVES independent blocks per workgroup, one per wavefront: a 256-thread workgroup is guaranteed to put its
      * four waves on the four SIMDs of the CU, which single-wave workgroups are not (they were observed to pile up). */
     __shared__ HuffShared shAll[HUFF_WAVES];
     const uint32_t waveInGroup = sfl( threadIdx.x >> 6 );   /* wave-uniform: keeps all decoder state in SGPRs */
     HuffShared& sh = shAll[waveInGroup];
-    const uint32_t b = blockIdx.x * HUFF_WAVES + waveInGroup;
-    if ( b >= n_blocks ) return;
+    /* longest-processing-time-first: slot i works on the block with the i-th largest compressed size, so the expensive
+     * (incompressible) blocks start first and the cheap ones fill the tail */
+    const uint32_t slot = blockIdx.x * HUFF_WAVES + waveInGroup;
+    if ( slot >= n_blocks ) return;
+    const uint32_t b = sfl( order[slot] );
     const uint32_t lane = threadIdx.x & 63;
     uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
     uint16_t* const symOut = sym_buf + (size_t)b * SYM_STRIDE;
@@ -515,7 +519,8 @@ k_mtf( BlockMeta* __restrict__       meta,
        const uint16_t* __restrict__  sym_buf,
        const uint8_t* __restrict__   stb_buf,
        uint8_t* __restrict__         l_buf,
-       uint32_t                      n_blocks )
+       uint32_t                      n_blocks,
+       const uint32_t* __restrict__  order )
 {
     __shared__ uint32_t listsAll[MTF_BLOCKS_PER_WG][64 * MTF_THREADS];   /* 32 KiB per block */
     __shared__ uint8_t curAll[MTF_BLOCKS_PER_WG][256];
@@ -529,8 +534,9 @@ k_mtf( BlockMeta* __restrict__       meta,
     uint32_t* const starts = startsAll[half];
     unsigned long long* const waveTotals = waveTotalsAll[half];
     uint32_t& firstError = firstErrorAll[half];
-    const uint32_t b = blockIdx.x * MTF_BLOCKS_PER_WG + half;
-    if ( b >= n_blocks ) return;   /* exited waves do not take part in later barriers */
+    const uint32_t slot = blockIdx.x * MTF_BLOCKS_PER_WG + half;
+    if ( slot >= n_blocks ) return;   /* exited waves do not take part in later barriers */
+    const uint32_t b = order[slot];
     const HuffMeta hm = hmeta[b];
     if ( !hm.active ) return;
     const uint32_t t = threadIdx.x % MTF_THREADS, lane = t & 63, wave = t >> 6;
