@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("BZ2_BENCH_CACHE", "/tmp/indexed_bzip2_amd_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 flow on ONE GPU: ranks share cuda:0 and extents travel via host memory")
     args = ap.parse_args()
 
     import torch   # first: the process must use ONE HIP runtime (torch's), the extension binds to the loaded one
@@ -140,10 +142,14 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
 
     def barrier():
         if world > 1:
@@ -161,7 +167,7 @@ def main():
 
     # compressed bytes resident in HBM before the timed region
     d_in = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
-    dec = m.Decoder(device=local_rank, max_batch_blocks=n_blocks)
+    dec = m.Decoder(device=device_index, max_batch_blocks=n_blocks)
     dec.set_input_device(d_in.data_ptr(), len(enc), keepalive=d_in)
 
     gather_buf = None
@@ -172,22 +178,13 @@ def main():
         nonlocal gather_buf
         if world == 1 or args.no_gather:
             return
+        from indexed_bzip2_amd.distributed import gather_extents
         mine = torch.as_tensor(_DevicePtr(dec.output_device_ptr(), total), device="cuda")
-        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([total], dtype=torch.int64, device="cuda"))
-        sizes = [int(s.item()) for s in sizes]
+        if args.backend == "gloo":
+            mine = mine.cpu()
+        buf, _sizes = gather_extents(mine, rank, world, gather_buf)
         if rank == 0:
-            need = sum(sizes[1:])
-            if gather_buf is None or gather_buf.numel() < need:
-                gather_buf = torch.empty(need, dtype=torch.uint8, device="cuda")
-            ops, pos = [], 0
-            for r in range(1, world):
-                ops.append(dist.P2POp(dist.irecv, gather_buf[pos:pos + sizes[r]], r))
-                pos += sizes[r]
-        else:
-            ops = [dist.P2POp(dist.isend, mine, 0)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+            gather_buf = buf
 
     def step():
         results, total = dec.decode_batch(offsets)
@@ -209,6 +206,10 @@ def main():
         stored = (stored << 1) | ((enc[b >> 3] >> (7 - (b & 7))) & 1)
     assert stream_crc == stored, f"checksum of block checksums {stream_crc:08x} != stream CRC in file {stored:08x}"
     # (the per-block CRCs cover every decoded byte; tests/ compare full payloads against the oracle at smaller sizes)
+    # the zero-copy tensor view used by the RCCL gather must see the same bytes as the C ABI's own copy-out
+    view = torch.as_tensor(_DevicePtr(dec.output_device_ptr(), total), device="cuda")
+    assert bytes(view[:4096].cpu().numpy()) == dec.copy_output(0, 4096)
+    assert bytes(view[total - 4096:].cpu().numpy()) == dec.copy_output(total - 4096, 4096)
 
     for _ in range(max(0, args.warmup - 1)):
         step()
@@ -231,7 +232,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
