@@ -20,6 +20,7 @@
 #include "../../include/mi355x_bz2.h"
 #include "bz2_kernels.hip.h"
 #include "bz2_stage1.hip.h"
+#include "bz2_walk.hip.h"
 
 using namespace bz2gpu;
 
@@ -54,6 +55,10 @@ struct mi355x_bz2_ctx
     uint32_t* dSegLen{ nullptr };
     uint32_t* dSegSucc{ nullptr };
     uint32_t* dSegOff{ nullptr };
+    WalkPlan* dPlan{ nullptr };
+    uint32_t* dWalkBlk{ nullptr };
+    uint32_t* dWalkPre{ nullptr };
+    bool useGridWalk{ false };
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
 
@@ -133,6 +138,9 @@ freeScratch( mi355x_bz2_ctx* c )
     (void)hipFree( c->dSegLen ); c->dSegLen = nullptr;
     (void)hipFree( c->dSegSucc ); c->dSegSucc = nullptr;
     (void)hipFree( c->dSegOff ); c->dSegOff = nullptr;
+    (void)hipFree( c->dPlan ); c->dPlan = nullptr;
+    (void)hipFree( c->dWalkBlk ); c->dWalkBlk = nullptr;
+    (void)hipFree( c->dWalkPre ); c->dWalkPre = nullptr;
     (void)hipHostFree( c->hMeta ); c->hMeta = nullptr;
     (void)hipHostFree( c->hOffsets ); c->hOffsets = nullptr;
     c->capacity = 0;
@@ -161,6 +169,9 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     HIP_TRY( c, hipMalloc( &c->dSegLen, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dSegSucc, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dSegOff, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dPlan, sizeof( WalkPlan ) ) );
+    HIP_TRY( c, hipMalloc( &c->dWalkBlk, ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dWalkPre, ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipHostMalloc( &c->hMeta, (size_t)cap * sizeof( BlockMeta ), hipHostMallocDefault ) );
     HIP_TRY( c, hipHostMalloc( &c->hOffsets, (size_t)cap * sizeof( uint64_t ), hipHostMallocDefault ) );
     c->capacity = cap;
@@ -186,7 +197,7 @@ namespace
 {
 const char* const KERNEL_NAMES[] = {
     "k_huff", "k_mtf", "k_bwt_build", "k_walk<false>", "k_link", "k_walk<true>", "k_replicate", "k_rle<false>",
-    "k_rle<true>", "k_crc"
+    "k_rle<true>", "k_crc", "k_walk_plan"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
 static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
@@ -271,6 +282,8 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
     {
         const char* v1 = std::getenv( "MI355X_BZ2_V1_STAGE1" );
         c->useV1Stage1 = v1 != nullptr && v1[0] == '1';
+        const char* gw = std::getenv( "MI355X_BZ2_GRID_WALK" );
+        c->useGridWalk = gw != nullptr && gw[0] == '1';
     }
     if ( hipSetDevice( device ) != hipSuccess
          || hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
@@ -429,12 +442,29 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
                       c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL, n, c->dOrder );
     }
     TIMED_LAUNCH( c, 2, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
-    const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );
-    TIMED_LAUNCH( c, 3, k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
-                  c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-    TIMED_LAUNCH( c, 4, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
-    TIMED_LAUNCH( c, 5, k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
-                  c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+    if ( c->useGridWalk ) {
+        /* one lane per segment, all blocks at once (kept for A/B: MI355X_BZ2_GRID_WALK=1) */
+        const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );
+        TIMED_LAUNCH( c, 3, k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
+                      c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+        TIMED_LAUNCH( c, 4, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
+        TIMED_LAUNCH( c, 5, k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
+                      c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
+        HIP_TRY( c, hipEventRecord( c->ev[20], c->stream ) );
+        HIP_TRY( c, hipEventRecord( c->ev[21], c->stream ) );
+    } else {
+        const char* wg = std::getenv( "MI355X_BZ2_WALK_WGS" );   /* tuning knob: workgroups per XCD */
+        const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0 ? (uint32_t)std::atoi( wg ) : WALK_WGS_PER_XCD;
+        const dim3 walkGrid( WALK_QUEUES * wgsPerXcd );
+        const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
+        const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
+        TIMED_LAUNCH( c, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, c->stream, c->dMeta, n, c->dPlan, c->dWalkBlk, c->dWalkPre );
+        TIMED_LAUNCH( c, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, c->stream,
+                      c->dMeta, c->dTab, c->dPlan, c->dWalkBlk, c->dWalkPre, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR, walkChunk );
+        TIMED_LAUNCH( c, 4, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
+        TIMED_LAUNCH( c, 5, k_walk2<true>, walkGrid, dim3( WALK_THREADS ), 0, c->stream,
+                      c->dMeta, c->dTab, c->dPlan, c->dWalkBlk, c->dWalkPre, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR, walkChunk );
+    }
     TIMED_LAUNCH( c, 6, k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
     TIMED_LAUNCH( c, 7, k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
     HIP_TRY( c, hipGetLastError() );
@@ -481,7 +511,7 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     float ms = 0;
     c->timings = {};
     c->timings.n_kernels = N_KERNELS;
-    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[2 * N_KERNELS - 1] ) == hipSuccess ) c->timings.ms_total = ms;
+    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[2 * 9 + 1] ) == hipSuccess ) c->timings.ms_total = ms;   /* k_huff start .. k_crc end */
     for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
         if ( hipEventElapsedTime( &ms, c->ev[2 * k], c->ev[2 * k + 1] ) == hipSuccess ) {
             c->timings.ms_kernel[k] = ms;

@@ -1,0 +1,174 @@
+/**
+ * bz2_walk.hip.h -- inverse-BWT walk, XCD-affine work-queue form (replaces the one-lane-per-segment grid k_walk).
+ *
+ * Why: PMC showed each of the 2 x 2.3 G four-byte gathers of the grid version pulling a full 64-B line across the fabric
+ * (FETCH_SIZE 127 GB per pass for 9 GB of tables): ~60 blocks' tables (230 MB) were in flight at once, so nothing
+ * stayed in an XCD's 4 MiB L2.  Here every block is assigned to ONE XCD queue (block i -> queue i mod 8), each
+ * workgroup reads its XCC id (s_getreg HW_REG_XCC_ID) and pulls chunks of consecutive segments from its own XCD's
+ * queue, and the grid is kept small (48 workgroups per XCD), so an XCD works on one or two 3.6 MB tables at a time and
+ * the gathers hit its L2.  Lanes refill from the chunk through an LDS counter, so a short segment does not idle its
+ * lane.  A workgroup whose queue is exhausted helps the other queues; nobody ever waits on another workgroup, every
+ * loop is bounded by atomic counters that only grow, so the grid always drains.  Placement affects speed only.
+ *
+ * Reference: the N-step dependent walk of BurrowsWheelerTransformData::decodeBlock, bzip2.hpp:872-879.
+ */
+#pragma once
+
+#include "bz2_kernels.hip.h"
+
+namespace bz2gpu
+{
+constexpr uint32_t WALK_THREADS = 256;
+constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
+constexpr uint32_t WALK_WGS_PER_XCD = 160;
+constexpr uint32_t WALK_QUEUES = 8;
+
+struct WalkPlan
+{
+    uint32_t q_begin[WALK_QUEUES + 1];   /* entry range of queue q in blk[] / pre[] */
+    uint32_t q_total[WALK_QUEUES];       /* segments in queue q */
+    uint32_t ctr[2][WALK_QUEUES];        /* [pass][queue]: next unclaimed segment (atomic) */
+    uint32_t pad[7];
+};
+
+/** One workgroup: lays out the queues (block i -> queue i mod 8) and zeroes the counters. */
+__global__ __launch_bounds__( 256 ) void
+k_walk_plan( const BlockMeta* __restrict__ meta, uint32_t n, WalkPlan* plan, uint32_t* blk, uint32_t* pre )
+{
+    __shared__ uint32_t begin[WALK_QUEUES + 1];
+    const uint32_t t = threadIdx.x;
+    if ( t == 0 ) {
+        uint32_t acc = 0;
+        for ( uint32_t q = 0; q < WALK_QUEUES; ++q ) {
+            begin[q] = acc;
+            acc += q < n ? ( n - q + WALK_QUEUES - 1 ) / WALK_QUEUES : 0;
+        }
+        begin[WALK_QUEUES] = acc;
+    }
+    __syncthreads();
+    if ( t <= WALK_QUEUES ) plan->q_begin[t] = begin[t];
+    if ( t < WALK_QUEUES ) {
+        uint32_t idx = begin[t], acc = 0;
+        for ( uint32_t i = t; i < n; i += WALK_QUEUES ) {
+            blk[idx] = i;
+            pre[idx] = acc;
+            acc += meta[i].walk_ok ? meta[i].nseg : 0u;
+            ++idx;
+        }
+        plan->q_total[t] = acc;
+        plan->ctr[0][t] = 0;
+        plan->ctr[1][t] = 0;
+    }
+}
+
+template<bool EMIT>
+__global__ __launch_bounds__( WALK_THREADS ) void
+k_walk2( const BlockMeta* __restrict__ meta,
+         const uint32_t* __restrict__  tab_buf,
+         WalkPlan*                     plan,
+         const uint32_t* __restrict__  blk,
+         const uint32_t* __restrict__  pre,
+         uint32_t*                     seg_len,
+         uint32_t*                     seg_succ,
+         const uint32_t*               seg_off,
+         uint8_t*                      r_buf,
+         uint32_t                      chunk )
+{
+    __shared__ uint32_t sBase, sNext, sK0;
+    const uint32_t tid = threadIdx.x;
+    uint32_t xcc;
+    asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"( xcc ) );
+    xcc &= WALK_QUEUES - 1;
+    constexpr uint32_t pass = EMIT ? 1u : 0u;
+
+    for ( uint32_t attempt = 0; attempt < WALK_QUEUES; ++attempt ) {
+        const uint32_t q = ( xcc + attempt ) & ( WALK_QUEUES - 1 );
+        const uint32_t qb = plan->q_begin[q], qe = plan->q_begin[q + 1];
+        const uint32_t total = plan->q_total[q];
+        if ( total == 0 ) continue;
+        for ( ;; ) {
+            __syncthreads();   /* everyone is done with sBase / sNext / sK0 of the previous chunk */
+            if ( tid == 0 ) {
+                const uint32_t base = atomicAdd( &plan->ctr[pass][q], chunk );
+                sBase = base;
+                sNext = WALK_THREADS;
+                /* last entry k in [qb, qe) with pre[k] <= base */
+                uint32_t lo = qb, hi = qe;
+                while ( hi - lo > 1 ) {
+                    const uint32_t mid = ( lo + hi ) >> 1;
+                    if ( pre[mid] <= base ) lo = mid; else hi = mid;
+                }
+                sK0 = lo;
+            }
+            __syncthreads();
+            const uint32_t base = sBase;
+            if ( base >= total ) break;   /* queue exhausted (the counter only grows) */
+            const uint32_t cnt = total - base < chunk ? total - base : chunk;
+            uint32_t k = sK0;
+            uint32_t curBlock = 0xFFFFFFFFu, N = 0, stride = 1, origPtr = 0, k0 = 0;
+            const uint32_t* tab = nullptr;
+            uint32_t my = tid;
+            while ( my < cnt ) {
+                const uint32_t flat = base + my;
+                while ( k + 1 < qe && flat >= pre[k + 1] ) ++k;
+                const uint32_t b = blk[k];
+                const uint32_t j = flat - pre[k];
+                if ( b != curBlock ) {
+                    curBlock = b;
+                    N = meta[b].n;
+                    stride = meta[b].seg_stride;
+                    origPtr = meta[b].orig_ptr;
+                    k0 = ( N + stride - 1 ) / stride;
+                    tab = tab_buf + (size_t)b * TAB_STRIDE;
+                }
+                const size_t sidx = (size_t)b * SEG_STRIDE + j;
+                uint32_t p = j < k0 ? j * stride : origPtr;
+                uint32_t e = tab[p];
+                uint32_t len = 0;
+                if constexpr ( EMIT ) {
+                    const uint32_t off = seg_off[sidx];
+                    if ( off != INVALID_OFF ) {
+                        uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
+                        /* bytes go to descending addresses; whole aligned dwords are written as one store */
+                        uint32_t a = N - 1 - off;      /* address of the next byte */
+                        uint32_t acc = 0, have = 0;    /* bytes collected for the dword that contains a+1.. */
+                        do {
+                            const uint32_t byte = e & 0xFFu;
+                            if ( have == 0 && ( a & 3u ) != 3u ) {
+                                R[a] = (uint8_t)byte;          /* unaligned head: shares its dword with a neighbour */
+                            } else {
+                                acc |= byte << ( 8 * ( a & 3u ) );
+                                ++have;
+                                if ( have == 4 ) {
+                                    *reinterpret_cast<uint32_t*>( R + a ) = acc;
+                                    acc = 0;
+                                    have = 0;
+                                }
+                            }
+                            --a;
+                            ++len;
+                            p = ( e >> 8 ) & LF_MASK;
+                            e = tab[p];
+                        } while ( !( e & MARK ) && len < N );
+                        /* tail: `have` bytes at addresses a+1 .. a+have */
+                        for ( uint32_t z = 0; z < have; ++z ) {
+                            const uint32_t addr = a + 1 + z;
+                            R[addr] = (uint8_t)( acc >> ( 8 * ( addr & 3u ) ) );
+                        }
+                    }
+                } else {
+                    do {
+                        ++len;
+                        p = ( e >> 8 ) & LF_MASK;
+                        e = tab[p];
+                    } while ( !( e & MARK ) && len < N );
+                    seg_len[sidx] = len;
+                    const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
+                    seg_succ[sidx] = ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu;
+                }
+                my = atomicAdd( &sNext, 1u );
+            }
+        }
+    }
+}
+}  // namespace bz2gpu
