@@ -48,7 +48,6 @@ struct mi355x_bz2_ctx
     uint16_t* dSym{ nullptr };
     uint8_t* dStb{ nullptr };
     HuffMeta* dHmeta{ nullptr };
-    bool useV1Stage1{ false };
     uint8_t* dL{ nullptr };
     uint32_t* dTab{ nullptr };
     uint8_t* dR{ nullptr };
@@ -58,7 +57,6 @@ struct mi355x_bz2_ctx
     WalkPlan* dPlan{ nullptr };
     uint32_t* dWalkBlk{ nullptr };
     uint32_t* dWalkPre{ nullptr };
-    bool useGridWalk{ false };
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
 
@@ -196,7 +194,7 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 namespace
 {
 const char* const KERNEL_NAMES[] = {
-    "k_huff", "k_mtf", "k_bwt_build", "k_walk<false>", "k_link", "k_walk<true>", "k_replicate", "k_rle<false>",
+    "k_huff", "k_mtf", "k_bwt_build", "k_walk2<false>", "k_link2", "k_walk2<true>", "k_replicate", "k_rle<false>",
     "k_rle<true>", "k_crc", "k_walk_plan"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
@@ -279,12 +277,6 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
     auto* c = new mi355x_bz2_ctx();
     c->device = device;
     c->flags = config != nullptr ? config->flags : 0;
-    {
-        const char* v1 = std::getenv( "MI355X_BZ2_V1_STAGE1" );
-        c->useV1Stage1 = v1 != nullptr && v1[0] == '1';
-        const char* gw = std::getenv( "MI355X_BZ2_GRID_WALK" );
-        c->useGridWalk = gw != nullptr && gw[0] == '1';
-    }
     if ( hipSetDevice( device ) != hipSuccess
          || hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
         delete c;
@@ -427,14 +419,10 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         HIP_TRY( c, hipMemcpyAsync( c->dOrder, c->hOrder, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
     }
 
-    if ( c->useV1Stage1 ) {
-        /* fused v1 kernel kept for A/B comparison (MI355X_BZ2_V1_STAGE1=1) */
-        TIMED_LAUNCH( c, 0, k_stage1, dim3( n ), dim3( 64 ), 0, c->stream,
-                      reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dSel, c->dL );
-        HIP_TRY( c, hipEventRecord( c->ev[2], c->stream ) );
-        HIP_TRY( c, hipEventRecord( c->ev[3], c->stream ) );
-    } else {
-        TIMED_LAUNCH( c, 0, k_huff, dim3( ( n + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), 0, c->stream,
+    {
+        const char* hl = std::getenv( "MI355X_BZ2_HUFF_LDS_PAD" );   /* tuning knob: extra LDS per workgroup lowers occupancy */
+        const uint32_t huffPad = hl != nullptr ? (uint32_t)std::atoi( hl ) : 0u;
+        TIMED_LAUNCH( c, 0, k_huff, dim3( ( n + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), huffPad, c->stream,
                       reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dHmeta, c->dSel,
                       c->dSym, c->dStb, n, c->dOrder );
         TIMED_LAUNCH( c, 1, k_mtf, dim3( ( n + MTF_BLOCKS_PER_WG - 1 ) / MTF_BLOCKS_PER_WG ),
@@ -442,17 +430,7 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
                       c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL, n, c->dOrder );
     }
     TIMED_LAUNCH( c, 2, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
-    if ( c->useGridWalk ) {
-        /* one lane per segment, all blocks at once (kept for A/B: MI355X_BZ2_GRID_WALK=1) */
-        const dim3 walkGrid( ( KMAX + 1 + 255 ) / 256, n );
-        TIMED_LAUNCH( c, 3, k_walk<false>, walkGrid, dim3( 256 ), 0, c->stream,
-                      c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-        TIMED_LAUNCH( c, 4, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
-        TIMED_LAUNCH( c, 5, k_walk<true>, walkGrid, dim3( 256 ), 0, c->stream,
-                      c->dMeta, c->dTab, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR );
-        HIP_TRY( c, hipEventRecord( c->ev[20], c->stream ) );
-        HIP_TRY( c, hipEventRecord( c->ev[21], c->stream ) );
-    } else {
+    {
         const char* wg = std::getenv( "MI355X_BZ2_WALK_WGS" );   /* tuning knob: workgroups per XCD */
         const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0 ? (uint32_t)std::atoi( wg ) : WALK_WGS_PER_XCD;
         const dim3 walkGrid( WALK_QUEUES * wgsPerXcd );
@@ -461,7 +439,7 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         TIMED_LAUNCH( c, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, c->stream, c->dMeta, n, c->dPlan, c->dWalkBlk, c->dWalkPre );
         TIMED_LAUNCH( c, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, c->stream,
                       c->dMeta, c->dTab, c->dPlan, c->dWalkBlk, c->dWalkPre, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR, walkChunk );
-        TIMED_LAUNCH( c, 4, k_link, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
+        TIMED_LAUNCH( c, 4, k_link2, dim3( n ), dim3( LINK_THREADS ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
         TIMED_LAUNCH( c, 5, k_walk2<true>, walkGrid, dim3( WALK_THREADS ), 0, c->stream,
                       c->dMeta, c->dTab, c->dPlan, c->dWalkBlk, c->dWalkPre, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR, walkChunk );
     }
@@ -490,7 +468,8 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         const BlockMeta& m = c->hMeta[i];
         mi355x_bz2_block_result& r = results[i];
         r.encoded_offset_bits = m.enc_off;
-        r.encoded_size_bits = m.enc_size;
+        /* set by the reference only after the symbol loop AND the origPtr check (bzip2.hpp:794-806); EOS: header only */
+        r.encoded_size_bits = ( m.status == ST_OK || m.status == ST_CRC ) ? m.enc_size : 0;
         r.decoded_size = m.status == ST_OK || m.status == ST_CRC ? m.decoded_size : 0;
         r.data_offset = m.out_off;
         r.header_crc = m.header_crc;

@@ -4,13 +4,10 @@
  * Pipeline for one batch of independent bzip2 blocks (reference: one BZ2BlockFetcher::decodeBlock call per block,
  * src/indexed_bzip2/BZ2BlockFetcher.hpp:85-138):
  *
- *   k_stage1      one wavefront per block: block header, symbol map, selectors, code lengths, canonical Huffman
- *                 LUTs in LDS, Huffman + RUNA/RUNB + MTF decode -> L column (u8[N])      bzip2.hpp:479-807
+ *   k_huff, k_mtf (bz2_stage1.hip.h)  header, tables, Huffman, RUNA/RUNB, MTF -> L column (u8[N])   bzip2.hpp:479-807
  *   k_bwt_build   per block: byte histogram, stable ranks -> packed LF table u32[N] = LF<<8 | byte | MARK
  *                 (coalesced writes; replaces the scatter of prepare(), bzip2.hpp:810-847)
- *   k_walk<false> one lane per SEGMENT of the permutation cycle: length + successor     } multi-start form of the
- *   k_link        orders the segments starting at origPtr, prefix sums their lengths    } N-step dependent walk of
- *   k_walk<true>  walks each segment again and writes the pre-RLE1 bytes in order       } bzip2.hpp:872-879
+ *   k_walk2<false>, k_link2, k_walk2<true> (bz2_walk.hip.h)  multi-segment form of the N-step walk  bzip2.hpp:872-879
  *   k_rle<false>  RLE1 as a 5-state scan: decoded size D per block                      bzip2.hpp:881-896
  *   k_rle<true>   expansion into the batch output buffer
  *   k_crc         bzip2 CRC-32 of the D bytes by chunk CRCs + GF(2) shift-combine        bzip2.hpp:59-91, 900-907
@@ -28,9 +25,9 @@ constexpr uint32_t MAX_N = 900000;            /* bzip2.hpp:416 dbuf size */
 constexpr uint32_t L_STRIDE = 900096;         /* bytes per block in the L and R buffers (multiple of 256) */
 constexpr uint32_t SEL_STRIDE = 32768;        /* bzip2.hpp:451 */
 constexpr uint32_t TAB_STRIDE = 1u << 20;     /* u32 entries per block: every 20-bit index stays in bounds */
-constexpr uint32_t KMAX = 8192;               /* max regular walk segments per block */
+constexpr uint32_t KMAX = 32768;              /* max regular walk segments per block (+1 for origPtr) */
 constexpr uint32_t SEG_STRIDE = KMAX + 64;
-constexpr uint32_t MIN_SEG_STRIDE = 32;
+constexpr uint32_t MIN_SEG_STRIDE = 16;
 constexpr int LUT_BITS = 9;
 constexpr uint32_t MARK = 0x80000000u;
 constexpr uint32_t LF_MASK = 0xFFFFFu;
@@ -165,28 +162,6 @@ struct BitRd
     }
 };
 
-/* -------------------------------------------------------------------------------------------------------------
- * Wave-cooperative move-to-front list: 256 entries, 4 per lane (entry 4*lane+k in byte k), held in one VGPR.
- * One literal costs a handful of VALU/DPP instructions independent of the index (the reference memmoves up to
- * 255 bytes, bzip2.hpp:781-785).  The list is initialised with symbolToByte so the value IS the output byte.
- * ------------------------------------------------------------------------------------------------------------- */
-__device__ __forceinline__ uint32_t
-mtf_step( uint32_t& m, uint32_t ii /* wave-uniform, 1..255 */, uint32_t lane )
-{
-    const uint32_t q = ii >> 2;
-    const uint32_t r = ii & 3;
-    const uint32_t mq = __builtin_amdgcn_readlane( m, q );
-    const uint32_t x = ( mq >> ( 8 * r ) ) & 0xFFu;
-    /* up[j] = m[j-1] (wave shift right by one lane) */
-    const uint32_t up = __builtin_amdgcn_update_dpp( 0u, m, 0x138 /* wave_shr:1 */, 0xF, 0xF, false );
-    const uint32_t carry = lane == 0 ? x : ( up >> 24 );
-    const uint32_t shifted = ( m << 8 ) | carry;
-    const uint32_t keep = r == 3 ? 0u : ( 0xFFFFFFFFu << ( 8 * ( r + 1 ) ) );
-    const uint32_t partial = ( shifted & ~keep ) | ( m & keep );
-    m = lane < q ? shifted : ( lane == q ? partial : m );
-    return x;
-}
-
 /** Lanes whose `key` (low `bits` bits) equals this lane's, restricted to `valid` lanes. */
 __device__ __forceinline__ uint64_t
 match_any( uint32_t key, int bits, bool valid )
@@ -216,341 +191,6 @@ k_bswap32( uint32_t* __restrict__ words, uint64_t n_words )
         v.x = __builtin_bswap32( v.x ); v.y = __builtin_bswap32( v.y );
         v.z = __builtin_bswap32( v.z ); v.w = __builtin_bswap32( v.w );
         *reinterpret_cast<uint4*>( words + i ) = v;
-    }
-}
-
-/* =============================================================================================================
- * k_stage1: one wavefront (64 threads) per bzip2 block.
- * ============================================================================================================= */
-struct Stage1Shared
-{
-    uint16_t lut[6][1 << LUT_BITS];   /* {len:5, sym:9}; 0 = not a short code */
-    uint16_t perm[6][260];            /* symbols sorted by (length, symbol): m_symbolsPerLength */
-    uint32_t first[6][24];            /* m_minimumCodeValuesPerLevel, indexed by length */
-    uint32_t count[6][24];            /* code-length frequencies */
-    uint32_t offs[6][24];             /* m_offsets, indexed by length */
-    uint32_t running[24];
-    uint8_t  lens[6][264];
-    uint16_t bitmap[16];
-    uint8_t  sym_to_byte[256];
-    uint32_t minmax[6];               /* minLen | maxLen << 8 */
-};
-
-__global__ __launch_bounds__( 64 ) void
-k_stage1( const uint32_t* __restrict__ in_words,
-          uint64_t                     in_size_bytes,
-          const uint64_t* __restrict__ offsets,
-          BlockMeta* __restrict__      meta,
-          uint8_t*                     sel_buf,
-          uint8_t* __restrict__        l_buf )
-{
-    __shared__ Stage1Shared sh;
-    const uint32_t b = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
-    uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
-
-    const uint64_t start = offsets[b];
-    BitRd br;
-    br.init( in_words, in_size_bytes, start );
-
-    int32_t status = ST_OK;
-    uint32_t headerCrc = 0, origPtr = 0, N = 0, nsym = 0;
-    int32_t isEos = 0, isEof = 0;
-    uint64_t encSize = 0;
-    uint32_t symbolCount = 0, groupCount = 0, nSel = 0;
-
-#define FAIL( code ) do { status = br.eof ? (int32_t)ST_EOF : (int32_t)( code ); goto finish; } while ( 0 )
-
-    /* ---- Block::readBlockHeader, bzip2.hpp:479-523 ---- */
-    if ( start > br.size_bits ) {
-        br.eof = true;
-        FAIL( ST_EOF );
-    }
-    {
-        const uint64_t hi = br.read( 24 );
-        const uint64_t lo = br.read( 24 );
-        const uint64_t magic = ( hi << 24 ) | lo;
-        headerCrc = br.read( 32 );
-        if ( br.eof ) FAIL( ST_EOF );
-        if ( magic == 0x177245385090ULL ) {
-            isEos = 1;
-            const uint32_t inByte = (uint32_t)( br.pos & 7 );
-            if ( inByte > 0 ) {
-                br.read( 8 - inByte );
-                if ( br.eof ) FAIL( ST_EOF );
-            }
-            encSize = br.pos - start;
-            isEof = br.pos >= br.size_bits;
-            goto finish;
-        }
-        if ( magic != 0x314159265359ULL ) FAIL( ST_BAD_MAGIC );
-        const uint32_t randomized = br.read( 1 );
-        if ( br.eof ) FAIL( ST_EOF );
-        if ( randomized ) FAIL( ST_RANDOMIZED );
-        origPtr = br.read( 24 );
-        if ( br.eof ) FAIL( ST_EOF );
-        if ( origPtr > MAX_N ) FAIL( ST_ORIGPTR_RANGE );
-    }
-
-    /* ---- Block::readSymbolMaps, bzip2.hpp:526-571 ---- */
-    {
-        const uint32_t used = br.read( 16 );
-        for ( uint32_t v = lane; v < 256; v += 64 ) sh.sym_to_byte[v] = 0;   /* fresh Block: zero-initialised */
-        for ( int i = 0; i < 16; ++i ) {
-            uint32_t bm = 0;
-            if ( used & ( 1u << ( 15 - i ) ) ) {
-                bm = br.read( 16 );
-            }
-            if ( lane == 0 ) sh.bitmap[i] = (uint16_t)bm;
-        }
-        __syncthreads();
-        uint32_t total = 0;
-        for ( int g = 0; g < 16; ++g ) total += __popc( sh.bitmap[g] );
-        symbolCount = total;
-        for ( uint32_t v = lane; v < 256; v += 64 ) {
-            const uint32_t g = v >> 4, j = v & 15;
-            const uint32_t bm = sh.bitmap[g];
-            if ( bm & ( 1u << ( 15 - j ) ) ) {
-                uint32_t rank = 0;
-                for ( uint32_t gg = 0; gg < g; ++gg ) rank += __popc( sh.bitmap[gg] );
-                rank += j == 0 ? 0 : __popc( bm >> ( 16 - j ) );
-                sh.sym_to_byte[rank] = (uint8_t)v;
-            }
-        }
-        __syncthreads();
-        if ( br.eof ) FAIL( ST_EOF );
-    }
-
-    /* ---- Block::readSelectors, bzip2.hpp:574-637 ---- */
-    {
-        groupCount = br.read( 3 );
-        if ( br.eof ) FAIL( ST_EOF );
-        if ( groupCount < 2 || groupCount > 6 ) FAIL( ST_GROUP_COUNT );
-        nSel = br.read( 15 );
-        if ( br.eof ) FAIL( ST_EOF );
-        if ( nSel == 0 ) FAIL( ST_SELECTOR_COUNT );
-        uint32_t mtfsel = 0x543210u;   /* nibble k = entry k */
-        uint32_t packed = 0;
-        for ( uint32_t i = 0; i < nSel; ++i ) {
-            br.refill();
-            if ( br.pos + 6 > br.size_bits ) {   /* peek<6> throws at EOF, BitReader.hpp:458-460 */
-                br.eof = true;
-                FAIL( ST_EOF );
-            }
-            const uint32_t bits6 = br.peek( 6 );
-            const uint32_t j = __clz( ~( bits6 << 26 ) );   /* leading ones, 6 if all set */
-            br.skip( j + 1 );
-            if ( j >= groupCount ) FAIL( ST_SELECTOR_UNARY );
-            const uint32_t shj = 4 * j;
-            const uint32_t val = ( mtfsel >> shj ) & 0xFu;
-            const uint32_t low = mtfsel & ( ( 1u << shj ) - 1u );
-            const uint32_t highMask = ~( ( 16u << shj ) - 1u );
-            mtfsel = ( mtfsel & highMask ) | ( low << 4 ) | val;
-            packed |= val << ( 8 * ( i & 3 ) );
-            if ( ( i & 3 ) == 3 || i + 1 == nSel ) {
-                if ( lane == 0 ) *reinterpret_cast<uint32_t*>( sel + ( i & ~3u ) ) = packed;
-                packed = 0;
-            }
-        }
-    }
-
-    /* ---- Block::readTrees, bzip2.hpp:644-685 ---- */
-    {
-        const uint32_t symCount = symbolCount + 2;
-        for ( uint32_t t = 0; t < groupCount; ++t ) {
-            uint32_t hh = br.read( 5 );
-            if ( br.eof ) FAIL( ST_EOF );
-            for ( uint32_t s = 0; s < symCount; ++s ) {
-                for ( ;; ) {
-                    if ( hh - 1u > 19u ) FAIL( ST_CODE_LENGTH );
-                    br.refill();
-                    const uint32_t b2 = br.peek( 2 );
-                    if ( b2 < 2 ) {
-                        if ( br.pos + 1 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
-                        br.skip( 1 );
-                        break;
-                    }
-                    if ( br.pos + 2 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
-                    hh += b2 == 2 ? 1u : 0xFFFFFFFFu;
-                    br.skip( 2 );
-                }
-                if ( lane == 0 ) sh.lens[t][s] = (uint8_t)hh;
-            }
-        }
-        __syncthreads();
-
-        /* ---- canonical Huffman tables: HuffmanCodingBase.hpp:46-149, HuffmanCodingSymbolsPerLength.hpp:41-95,
-         *      HuffmanCodingShortBitsCached.hpp:39-96 (the LUT) ---- */
-        for ( uint32_t t = 0; t < groupCount; ++t ) {
-            /* length frequencies: lane l counts symbols of length l */
-            uint32_t c = 0;
-            if ( lane >= 1 && lane <= 20 ) {
-                for ( uint32_t s = 0; s < symCount; ++s ) c += sh.lens[t][s] == lane;
-            }
-            if ( lane < 24 ) sh.count[t][lane] = c;
-            __syncthreads();
-            uint32_t minLen = 0, maxLen = 0;
-            for ( uint32_t l = 1; l <= 20; ++l ) {
-                if ( sh.count[t][l] != 0 ) {
-                    if ( minLen == 0 ) minLen = l;
-                    maxLen = l;
-                }
-            }
-            /* checkCodeLengthFrequencies (CHECK_OPTIMALITY = false): reject over-subscribed length sets */
-            {
-                uint32_t unused = 1u << minLen;
-                bool bad = false;
-                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
-                    const uint32_t f = sh.count[t][l];
-                    if ( f > unused ) { bad = true; break; }
-                    unused = ( unused - f ) * 2u;
-                }
-                if ( bad ) FAIL( ST_HUFFMAN_LENGTHS );
-            }
-            /* minimum code value and symbol offset per length */
-            if ( lane == 0 ) {
-                uint32_t minCode = 0, sum = 0;
-                for ( uint32_t l = 0; l < 24; ++l ) { sh.first[t][l] = 0; sh.offs[t][l] = 0; }
-                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
-                    minCode = ( minCode + ( l > minLen ? sh.count[t][l - 1] : 0u ) ) << 1;
-                    if ( l == minLen ) minCode = 0;
-                    sh.first[t][l] = minCode;
-                    sh.offs[t][l] = sum;
-                    sh.running[l] = sum;
-                    sum += sh.count[t][l];
-                }
-                sh.minmax[t] = minLen | ( maxLen << 8 );
-            }
-            __syncthreads();
-            /* symbols sorted by (length, symbol index): stable multi-split, 64 symbols per step */
-            for ( uint32_t base = 0; base < symCount; base += 64 ) {
-                const uint32_t s = base + lane;
-                const bool valid = s < symCount;
-                const uint32_t len = valid ? sh.lens[t][s] : 0u;
-                const uint64_t same = match_any( len, 5, valid );
-                const uint32_t rank = popc_below( same, lane );
-                uint32_t basePos = 0;
-                if ( valid ) basePos = sh.running[len];
-                if ( valid ) sh.perm[t][basePos + rank] = (uint16_t)s;
-                __syncthreads();
-                if ( valid && rank == 0 ) sh.running[len] = basePos + (uint32_t)__popcll( same );
-                __syncthreads();
-            }
-            /* LUT: every LUT_BITS-bit prefix -> {len, sym} of the code it starts with (0 if longer / none) */
-            const uint32_t lutMax = maxLen < (uint32_t)LUT_BITS ? maxLen : (uint32_t)LUT_BITS;
-            for ( uint32_t e = lane; e < ( 1u << LUT_BITS ); e += 64 ) {
-                uint32_t val = 0;
-                for ( uint32_t l = minLen; l <= lutMax; ++l ) {
-                    const uint32_t code = e >> ( LUT_BITS - l );
-                    const uint32_t d = code - sh.first[t][l];
-                    if ( d < sh.count[t][l] ) {
-                        val = l | ( (uint32_t)sh.perm[t][sh.offs[t][l] + d] << 5 );
-                        break;
-                    }
-                }
-                sh.lut[t][e] = (uint16_t)val;
-            }
-            __syncthreads();
-        }
-    }
-
-    /* ---- Block::readBlockData, bzip2.hpp:691-807: Huffman + RUNA/RUNB + MTF -> L ---- */
-    {
-        uint32_t m;   /* MTF list, 4 entries per lane, pre-mapped through symbolToByte */
-        {
-            const uint32_t* s2b = reinterpret_cast<const uint32_t*>( sh.sym_to_byte );
-            m = s2b[lane];
-        }
-        uint32_t groupLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
-        uint32_t runPos = 0, hh = 0, cnt = 0;
-        for ( ;; ) {
-            if ( groupLeft == 0 ) {
-                if ( selIdx >= nSel ) FAIL( ST_SELECTOR_OVERRUN );
-                tcur = sfl( (uint32_t)sel[selIdx] );
-                ++selIdx;
-                groupLeft = 50;
-                tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
-            }
-            --groupLeft;
-            br.refill();
-            const uint32_t idx = br.peek( LUT_BITS );
-            const uint32_t e = sfl( (uint32_t)sh.lut[tcur][idx] );
-            uint32_t len, sym;
-            if ( e != 0 ) {
-                len = e & 31u;
-                sym = e >> 5;
-            } else {
-                /* decodeLong, HuffmanCodingShortBitsCached.hpp:117-150 */
-                len = 0;
-                sym = 0;
-                for ( uint32_t l = LUT_BITS + 1; l <= tMaxLen; ++l ) {
-                    const uint32_t code = br.peek( l );
-                    const uint32_t d = code - sfl( sh.first[tcur][l] );
-                    if ( d < sfl( sh.count[tcur][l] ) ) {
-                        sym = sfl( (uint32_t)sh.perm[tcur][sfl( sh.offs[tcur][l] ) + d] );
-                        len = l;
-                        break;
-                    }
-                }
-                if ( len == 0 ) {
-                    if ( br.pos + tMaxLen > br.size_bits ) br.eof = true;
-                    FAIL( ST_INVALID_CODE );
-                }
-            }
-            br.skip( len );
-            if ( br.pos > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
-            ++nsym;
-
-            if ( sym <= 1 ) {   /* RUNA / RUNB, bzip2.hpp:726-743 */
-                if ( runPos == 0 ) { runPos = 1; hh = 0; }
-                hh += runPos << sym;
-                runPos <<= 1;
-                continue;
-            }
-            if ( runPos != 0 ) {
-                runPos = 0;
-                /* the reference adds in uint32 (wraps, then overruns its buffer); any wrap is an overflow here */
-                if ( (uint64_t)cnt + hh > MAX_N ) FAIL( ST_RUN_OVERFLOW );
-                const uint32_t uc = sfl( m ) & 0xFFu;
-                for ( uint32_t i = lane; i < hh; i += 64 ) L[cnt + i] = (uint8_t)uc;
-                cnt += hh;
-            }
-            if ( sym > symbolCount ) break;   /* end of block */
-            if ( cnt >= MAX_N ) FAIL( ST_DATA_OVERFLOW );
-            const uint32_t x = mtf_step( m, sym - 1, lane );
-            if ( lane == 0 ) L[cnt] = (uint8_t)x;
-            ++cnt;
-        }
-        N = cnt;
-        if ( origPtr >= N ) FAIL( ST_ORIGPTR_DATA );
-        encSize = br.pos - start;
-    }
-
-finish:
-#undef FAIL
-    if ( lane == 0 ) {
-        BlockMeta mt;
-        mt.enc_off = start;
-        mt.enc_size = encSize;
-        mt.decoded_size = 0;
-        mt.out_off = 0;
-        mt.header_crc = headerCrc;
-        mt.computed_crc = 0xFFFFFFFFu;   /* BlockData::calculatedCRC default */
-        mt.n = N;
-        mt.orig_ptr = origPtr;
-        mt.nsym = nsym;
-        mt.is_eos = isEos;
-        mt.is_eof = isEof;
-        mt.status = status;
-        uint32_t stride = ( N + KMAX - 1 ) / KMAX;
-        if ( stride < MIN_SEG_STRIDE ) stride = MIN_SEG_STRIDE;
-        const uint32_t k0 = ( N + stride - 1 ) / stride;
-        mt.seg_stride = stride;
-        mt.nseg = k0 + ( ( N > 0 && origPtr % stride != 0 ) ? 1u : 0u );
-        mt.walk_ok = ( status == ST_OK && !isEos && N > 0 ) ? 1u : 0u;
-        mt.cycle_len = 0;
-        meta[b] = mt;
     }
 }
 
@@ -641,114 +281,6 @@ k_bwt_build( const BlockMeta* __restrict__ meta,
             const bool mark = ( i % stride == 0 ) || ( i == origPtr );
             tab[i] = ( lf << 8 ) | key | ( mark ? MARK : 0u );
             if ( rank == 0 ) hist[wave][key] = basePos + (uint32_t)__popcll( same );
-        }
-    }
-}
-
-/* =============================================================================================================
- * k_walk: the N-step dependent chain of bzip2.hpp:872-879 cut into <= KMAX+1 independent segments.
- * Segment starts (MARKed table entries) are every `stride`-th index plus origPtr.  Because LF is a permutation
- * every walk returns to a marked entry, so each lane terminates after at most N steps.
- *   EMIT=false: record segment length and successor segment.
- *   EMIT=true : write the bytes of the segment at their final position in the pre-RLE1 stream R.
- * ============================================================================================================= */
-__device__ __forceinline__ uint32_t
-seg_start( uint32_t j, uint32_t k0, uint32_t stride, uint32_t origPtr )
-{
-    return j < k0 ? j * stride : origPtr;
-}
-
-template<bool EMIT>
-__global__ __launch_bounds__( 256 ) void
-k_walk( const BlockMeta* __restrict__ meta,
-        const uint32_t* __restrict__  tab_buf,
-        uint32_t*                     seg_len,
-        uint32_t*                     seg_succ,
-        const uint32_t*               seg_off,
-        uint8_t*                      r_buf )
-{
-    const uint32_t b = blockIdx.y;
-    const BlockMeta mt = meta[b];
-    if ( !mt.walk_ok ) return;
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if ( j >= mt.nseg ) return;
-    const uint32_t N = mt.n, stride = mt.seg_stride, origPtr = mt.orig_ptr;
-    const uint32_t k0 = ( N + stride - 1 ) / stride;
-    const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
-    const size_t sidx = (size_t)b * SEG_STRIDE + j;
-
-    uint32_t p = seg_start( j, k0, stride, origPtr );
-    uint32_t e = tab[p];
-    uint32_t len = 0;
-    if constexpr ( EMIT ) {
-        const uint32_t off = seg_off[sidx];
-        if ( off == INVALID_OFF ) return;
-        uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
-        uint32_t pos = N - 1 - off;
-        do {
-            R[pos] = (uint8_t)e;
-            --pos;
-            ++len;
-            p = ( e >> 8 ) & LF_MASK;
-            e = tab[p];
-        } while ( !( e & MARK ) && len < N );
-    } else {
-        do {
-            ++len;
-            p = ( e >> 8 ) & LF_MASK;
-            e = tab[p];
-        } while ( !( e & MARK ) && len < N );
-        seg_len[sidx] = len;
-        const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
-        seg_succ[sidx] = ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu;
-    }
-}
-
-/* =============================================================================================================
- * k_link: order the segments along the cycle starting at origPtr and prefix-sum their lengths.
- * LF is always a permutation, so the chain returns to its first segment after c = (cycle length) steps.  For
- * ordinary data c == N.  For periodic data (e.g. "abab...": the sorted rotations repeat) the permutation splits
- * into N/c cycles and the reference's N-step walk (bzip2.hpp:872-879) simply goes round the origPtr cycle N/c
- * times -- the output is the first period repeated.  Segments off the cycle keep INVALID_OFF and are not emitted;
- * k_replicate copies the first period into the rest of the stream.  Corrupt data takes the same path and is
- * caught by the CRC, exactly as in the reference.
- * ============================================================================================================= */
-__global__ __launch_bounds__( 256 ) void
-k_link( BlockMeta*                   meta,
-        const uint32_t* __restrict__ seg_len,
-        const uint32_t* __restrict__ seg_succ,
-        uint32_t* __restrict__       seg_off )
-{
-    __shared__ uint32_t slen[SEG_STRIDE];
-    __shared__ uint16_t ssucc[SEG_STRIDE];
-    const uint32_t b = blockIdx.x;
-    const BlockMeta mt = meta[b];
-    if ( !mt.walk_ok ) return;
-    const uint32_t nseg = mt.nseg, N = mt.n, stride = mt.seg_stride, origPtr = mt.orig_ptr;
-    const uint32_t k0 = ( N + stride - 1 ) / stride;
-    const size_t base = (size_t)b * SEG_STRIDE;
-    for ( uint32_t j = threadIdx.x; j < nseg; j += 256 ) {
-        slen[j] = seg_len[base + j];
-        const uint32_t s = seg_succ[base + j];
-        ssucc[j] = (uint16_t)( s < nseg ? s : 0xFFFFu );
-        seg_off[base + j] = INVALID_OFF;
-    }
-    __syncthreads();
-    if ( threadIdx.x == 0 ) {
-        const uint32_t first = ( origPtr % stride != 0 ) ? k0 : origPtr / stride;
-        uint32_t cur = first, off = 0, visited = 0;
-        bool ok = true;
-        do {
-            seg_off[base + cur] = off;
-            off += slen[cur];
-            cur = ssucc[cur];
-            ++visited;
-            if ( cur == 0xFFFFu || visited > nseg || off > N ) { ok = false; break; }
-        } while ( cur != first );
-        meta[b].cycle_len = off;
-        if ( !ok || off == 0 ) {   /* unreachable for a permutation: guards against table corruption */
-            meta[b].status = ST_CRC;
-            meta[b].walk_ok = 0;
         }
     }
 }

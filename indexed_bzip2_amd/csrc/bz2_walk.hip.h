@@ -20,7 +20,7 @@ namespace bz2gpu
 {
 constexpr uint32_t WALK_THREADS = 256;
 constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
-constexpr uint32_t WALK_WGS_PER_XCD = 160;
+constexpr uint32_t WALK_WGS_PER_XCD = 256;
 constexpr uint32_t WALK_QUEUES = 8;
 
 struct WalkPlan
@@ -58,6 +58,112 @@ k_walk_plan( const BlockMeta* __restrict__ meta, uint32_t n, WalkPlan* plan, uin
         plan->q_total[t] = acc;
         plan->ctr[0][t] = 0;
         plan->ctr[1][t] = 0;
+    }
+}
+
+/* =============================================================================================================
+ * k_link2: order the segments along the cycle that starts at origPtr and give each its output offset.
+ * LF is always a permutation, so the successor chain returns to its first segment after c = (cycle length) steps.
+ * For ordinary data c == N.  For periodic data (e.g. "abab...": the sorted rotations repeat) the permutation splits
+ * into N/c cycles and the reference's N-step walk (bzip2.hpp:872-879) goes round the origPtr cycle N/c times: the
+ * output is the first period repeated (k_replicate).  Segments off the cycle keep INVALID_OFF and are not emitted.
+ * Corrupt data takes the same path and is caught by the CRC, exactly as in the reference.
+ *
+ * With up to 32 769 segments the chain is itself cut at SPLITTERS (every 128th segment id + the first segment): each
+ * lane follows the successors from its splitter to the next splitter (successors in LDS as u16), lane 0 links the
+ * <= 257 sub-chains, and every lane walks its sub-chain again to write the offsets -- the same multi-start idea as the
+ * byte walk, one level up.
+ * ============================================================================================================= */
+constexpr uint32_t LINK_THREADS = 256;
+constexpr uint32_t LINK_SPLIT = 128;
+constexpr uint32_t LINK_MAX_SUB = KMAX / LINK_SPLIT + 2;   /* 258 */
+
+__global__ __launch_bounds__( LINK_THREADS ) void
+k_link2( BlockMeta*                   meta,
+         const uint32_t* __restrict__ seg_len,
+         const uint32_t* __restrict__ seg_succ,
+         uint32_t* __restrict__       seg_off )
+{
+    __shared__ uint16_t ssucc[SEG_STRIDE];          /* 64 KiB */
+    __shared__ uint32_t subLen[LINK_MAX_SUB];       /* bytes covered by sub-chain s */
+    __shared__ uint16_t subNext[LINK_MAX_SUB];      /* sub-chain that follows (index), 0xFFFF if broken */
+    __shared__ uint32_t subOff[LINK_MAX_SUB];       /* output offset of the sub-chain, INVALID_OFF if off the cycle */
+    const uint32_t b = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t nseg = mt.nseg, N = mt.n, stride = mt.seg_stride, origPtr = mt.orig_ptr;
+    const uint32_t k0 = ( N + stride - 1 ) / stride;
+    const size_t base = (size_t)b * SEG_STRIDE;
+    const uint32_t first = ( origPtr % stride != 0 ) ? k0 : origPtr / stride;
+    const uint32_t tid = threadIdx.x;
+
+    for ( uint32_t j = tid; j < nseg; j += LINK_THREADS ) {
+        const uint32_t s = seg_succ[base + j];
+        ssucc[j] = (uint16_t)( s < nseg ? s : 0xFFFFu );
+        seg_off[base + j] = INVALID_OFF;
+    }
+    /* sub-chain s < nSplit starts at segment s * LINK_SPLIT; sub-chain nSplit starts at `first` (unless that is a
+     * multiple of LINK_SPLIT already) */
+    const uint32_t nSplit = ( nseg + LINK_SPLIT - 1 ) / LINK_SPLIT;
+    const bool firstExtra = first % LINK_SPLIT != 0;
+    const uint32_t nSub = nSplit + ( firstExtra ? 1u : 0u );
+    const auto splitterOf = [&] ( uint32_t seg ) -> uint32_t {   /* sub-chain index if seg starts one, else 0xFFFF */
+        if ( seg == first && firstExtra ) return nSplit;
+        return seg % LINK_SPLIT == 0 ? seg / LINK_SPLIT : 0xFFFFu;
+    };
+    for ( uint32_t s = tid; s < LINK_MAX_SUB; s += LINK_THREADS ) subOff[s] = INVALID_OFF;
+    __syncthreads();
+
+    /* pass 1: length and successor of every sub-chain */
+    for ( uint32_t s = tid; s < nSub; s += LINK_THREADS ) {
+        uint32_t cur = s < nSplit ? s * LINK_SPLIT : first;
+        uint32_t sum = 0, steps = 0, nextSub = 0xFFFFu;
+        for ( ;; ) {
+            sum += seg_len[base + cur];
+            cur = ssucc[cur];
+            ++steps;
+            if ( cur == 0xFFFFu || steps > nseg ) break;           /* broken chain (cannot happen for a permutation) */
+            nextSub = splitterOf( cur );
+            if ( nextSub != 0xFFFFu ) break;
+        }
+        subLen[s] = sum;
+        subNext[s] = (uint16_t)nextSub;
+    }
+    __syncthreads();
+
+    /* link the sub-chains starting at the one that begins with `first` */
+    if ( tid == 0 ) {
+        const uint32_t start = firstExtra ? nSplit : first / LINK_SPLIT;
+        uint32_t s = start, off = 0, visited = 0;
+        bool ok = true;
+        do {
+            subOff[s] = off;
+            off += subLen[s];
+            s = subNext[s];
+            ++visited;
+            if ( s == 0xFFFFu || visited > nSub || off > N ) { ok = false; break; }
+        } while ( s != start );
+        meta[b].cycle_len = off;
+        if ( !ok || off == 0 ) {   /* unreachable for a permutation: guards against table corruption */
+            meta[b].status = ST_CRC;
+            meta[b].walk_ok = 0;
+        }
+    }
+    __syncthreads();
+
+    /* pass 2: offsets of the segments of every sub-chain that lies on the cycle */
+    for ( uint32_t s = tid; s < nSub; s += LINK_THREADS ) {
+        uint32_t off = subOff[s];
+        if ( off == INVALID_OFF ) continue;
+        uint32_t cur = s < nSplit ? s * LINK_SPLIT : first;
+        uint32_t steps = 0;
+        for ( ;; ) {
+            seg_off[base + cur] = off;
+            off += seg_len[base + cur];
+            cur = ssucc[cur];
+            ++steps;
+            if ( cur == 0xFFFFu || steps > nseg || splitterOf( cur ) != 0xFFFFu ) break;
+        }
     }
 }
 
