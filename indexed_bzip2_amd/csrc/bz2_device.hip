@@ -425,8 +425,7 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         TIMED_LAUNCH( c, 0, k_huff, dim3( ( n + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), huffPad, c->stream,
                       reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dHmeta, c->dSel,
                       c->dSym, c->dStb, n, c->dOrder );
-        TIMED_LAUNCH( c, 1, k_mtf, dim3( ( n + MTF_BLOCKS_PER_WG - 1 ) / MTF_BLOCKS_PER_WG ),
-                      dim3( MTF_THREADS * MTF_BLOCKS_PER_WG ), 0, c->stream,
+        TIMED_LAUNCH( c, 1, k_mtf, dim3( n ), dim3( MTF_THREADS ), 0, c->stream,
                       c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL, n, c->dOrder );
     }
     TIMED_LAUNCH( c, 2, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );

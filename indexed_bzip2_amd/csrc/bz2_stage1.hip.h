@@ -24,8 +24,9 @@ namespace bz2gpu
 {
 constexpr uint32_t SYM_STRIDE = 900224;       /* u16 symbols per block (n_sym <= N + 1 <= 900001 for valid blocks) */
 constexpr uint32_t SYM_CAP = 900096;
-constexpr uint32_t MTF_THREADS = 128;      /* lanes (= chunks) per block in k_mtf */
-constexpr uint32_t MTF_BLOCKS_PER_WG = 2;  /* 256-thread workgroups: all four SIMDs of a CU get a wave */
+constexpr uint32_t MTF_THREADS = 256;      /* lanes (= chunks) per block in k_mtf: one workgroup per block */
+constexpr uint32_t MTF_LANE_STRIDE = 272;  /* bytes between the lists of consecutive lanes: 256 + 16, so that the 16-byte
+                                              accesses of the 16 lanes served together fall on 64 distinct banks */
 constexpr uint32_t HUFF_WAVES = 1;      /* independent blocks (one per wavefront) per k_huff workgroup */
 
 /** Orders LDS traffic between the lanes of ONE wavefront (no s_barrier: the waves of a k_huff workgroup are independent). */
@@ -495,23 +496,71 @@ finish:
 
 /* ============================================================================================================= */
 
-/** Move entry `ii` of this lane's list to the front; returns the entry.  Dword k of lane t is lists[k * MTF_THREADS + t]. */
+/** Move entry `ii` of this lane's list to the front; returns the entry.  `mine` = this lane's 256-byte list in LDS
+ * (16-byte aligned): entries below `ii` shift up by one byte, four dwords (one ds_read_b128 / ds_write_b128) per trip. */
 __device__ __forceinline__ uint32_t
-mtf_lane_move( uint32_t* lists, uint32_t t, uint32_t ii )
+mtf_lane_move( uint4* mine, uint32_t ii )
 {
-    const uint32_t q = ii >> 2, r = ii & 3;
-    const uint32_t dq = lists[q * MTF_THREADS + t];
+    const uint32_t q = ii >> 2, r = ii & 3;   /* dword and byte of the entry */
+    const uint32_t q4 = q >> 2, r4 = q & 3;   /* uint4 that holds dword q, position inside it */
+    /* the entry itself (read first: the group that holds it is not touched by the loop below) goes to the front */
+    const uint4 a = mine[q4];
+    const uint32_t dq = r4 == 0 ? a.x : ( r4 == 1 ? a.y : ( r4 == 2 ? a.z : a.w ) );
     const uint32_t x = ( dq >> ( 8 * r ) ) & 0xFFu;
     uint32_t carry = x;
-    for ( uint32_t k = 0; k < q; ++k ) {
-        const uint32_t old = lists[k * MTF_THREADS + t];
-        lists[k * MTF_THREADS + t] = ( old << 8 ) | carry;
-        carry = old >> 24;
+    for ( uint32_t k = 0; k < q4; ++k ) {
+        const uint4 g = mine[k];
+        uint4 m;
+        m.x = ( g.x << 8 ) | carry;
+        m.y = ( g.y << 8 ) | ( g.x >> 24 );
+        m.z = ( g.z << 8 ) | ( g.y >> 24 );
+        m.w = ( g.w << 8 ) | ( g.z >> 24 );
+        carry = g.w >> 24;
+        mine[k] = m;
     }
+    /* last group: dwords 0..r4-1 shift completely, dword r4 up to byte r, the rest stays */
+    uint4 n = a;
+    uint32_t c = carry;
+    if ( r4 > 0 ) { n.x = ( a.x << 8 ) | c; c = a.x >> 24; }
+    if ( r4 > 1 ) { n.y = ( a.y << 8 ) | c; c = a.y >> 24; }
+    if ( r4 > 2 ) { n.z = ( a.z << 8 ) | c; c = a.z >> 24; }
     const uint32_t lowMask = r == 3 ? 0xFFFFFFFFu : ( ( 1u << ( 8 * ( r + 1 ) ) ) - 1u );
-    lists[q * MTF_THREADS + t] = ( ( ( dq << 8 ) | carry ) & lowMask ) | ( dq & ~lowMask );
+    const uint32_t part = ( ( ( dq << 8 ) | c ) & lowMask ) | ( dq & ~lowMask );
+    if ( r4 == 0 ) n.x = part; else if ( r4 == 1 ) n.y = part; else if ( r4 == 2 ) n.z = part; else n.w = part;
+    mine[q4] = n;
     return x;
 }
+
+/** Per-lane sequential reader of the u16 symbol stream: 8 symbols (16 bytes) per load, the next 16 bytes already in
+ * flight, so the symbol loop does not wait for a global load per symbol. */
+struct SymStream
+{
+    const uint16_t* p;
+    uint32_t base;       /* index of cur's first symbol (multiple of 8) */
+    uint4 cur, next;
+
+    __device__ __forceinline__ void
+    init( const uint16_t* symbols, uint32_t begin )
+    {
+        p = symbols;
+        base = begin & ~7u;
+        cur = *reinterpret_cast<const uint4*>( p + base );          /* the symbol buffer is padded past n */
+        next = *reinterpret_cast<const uint4*>( p + base + 8 );
+    }
+
+    __device__ __forceinline__ uint32_t
+    get( uint32_t i )   /* i must advance by one per call */
+    {
+        if ( i - base >= 8 ) {
+            base += 8;
+            cur = next;
+            next = *reinterpret_cast<const uint4*>( p + base + 8 );
+        }
+        const uint32_t idx = i - base;
+        const uint64_t half = idx < 4 ? ( (uint64_t)cur.y << 32 | cur.x ) : ( (uint64_t)cur.w << 32 | cur.z );
+        return (uint32_t)( half >> ( 16 * ( idx & 3u ) ) ) & 0xFFFFu;
+    }
+};
 
 /** Per-lane write combiner for a sequential byte stream: whole aligned dwords go out as one store (byte-granular
  * scattered stores cost a full write request each: 43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE).  Only the
@@ -561,7 +610,7 @@ struct ByteSink
     }
 };
 
-__global__ __launch_bounds__( MTF_THREADS * MTF_BLOCKS_PER_WG ) void
+__global__ __launch_bounds__( MTF_THREADS ) void
 k_mtf( BlockMeta* __restrict__       meta,
        const HuffMeta* __restrict__  hmeta,
        const uint16_t* __restrict__  sym_buf,
@@ -570,27 +619,22 @@ k_mtf( BlockMeta* __restrict__       meta,
        uint32_t                      n_blocks,
        const uint32_t* __restrict__  order )
 {
-    __shared__ uint32_t listsAll[MTF_BLOCKS_PER_WG][64 * MTF_THREADS];   /* 32 KiB per block */
-    __shared__ uint8_t curAll[MTF_BLOCKS_PER_WG][256];
-    __shared__ uint32_t startsAll[MTF_BLOCKS_PER_WG][MTF_THREADS + 1];
-    __shared__ unsigned long long waveTotalsAll[MTF_BLOCKS_PER_WG][MTF_THREADS / 64];
-    __shared__ uint32_t firstErrorAll[MTF_BLOCKS_PER_WG];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[MTF_THREADS * MTF_LANE_STRIDE];   /* 68 KiB */
+    __shared__ uint8_t cur[256];
+    __shared__ uint32_t starts[MTF_THREADS + 1];
+    __shared__ unsigned long long waveTotals[MTF_THREADS / 64];
+    __shared__ uint32_t firstError;
 
-    const uint32_t half = threadIdx.x / MTF_THREADS;
-    uint32_t* const lists = listsAll[half];
-    uint8_t* const cur = curAll[half];
-    uint32_t* const starts = startsAll[half];
-    unsigned long long* const waveTotals = waveTotalsAll[half];
-    uint32_t& firstError = firstErrorAll[half];
-    const uint32_t slot = blockIdx.x * MTF_BLOCKS_PER_WG + half;
-    if ( slot >= n_blocks ) return;   /* exited waves do not take part in later barriers */
+    const uint32_t slot = blockIdx.x;
+    if ( slot >= n_blocks ) return;
     const uint32_t b = order[slot];
     const HuffMeta hm = hmeta[b];
     if ( !hm.active ) return;
-    const uint32_t t = threadIdx.x % MTF_THREADS, lane = t & 63, wave = t >> 6;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t n = hm.n_stored;
     const uint16_t* const sym = sym_buf + (size_t)b * SYM_STRIDE;
     uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
+    uint4* const mine = reinterpret_cast<uint4*>( listBytes + t * MTF_LANE_STRIDE );
 
     /* chunk boundaries: never inside a RUNA/RUNB digit sequence */
     const uint32_t S = ( n + MTF_THREADS - 1 ) / MTF_THREADS;
@@ -599,9 +643,12 @@ k_mtf( BlockMeta* __restrict__       meta,
     starts[t] = begin;
     if ( t == 0 ) { starts[MTF_THREADS] = n; firstError = 0xFFFFFFFFu; }
     cur[t] = stb_buf[(size_t)b * 256 + t];
-    cur[t + 128] = stb_buf[(size_t)b * 256 + t + 128];
-    for ( uint32_t k = 0; k < 64; ++k ) {
-        lists[k * MTF_THREADS + t] = ( 4 * k ) | ( ( 4 * k + 1 ) << 8 ) | ( ( 4 * k + 2 ) << 16 ) | ( ( 4 * k + 3 ) << 24 );
+    for ( uint32_t k = 0; k < 16; ++k ) {
+        const uint32_t e = 16 * k;
+        mine[k] = make_uint4( ( e ) | ( ( e + 1 ) << 8 ) | ( ( e + 2 ) << 16 ) | ( ( e + 3 ) << 24 ),
+                              ( e + 4 ) | ( ( e + 5 ) << 8 ) | ( ( e + 6 ) << 16 ) | ( ( e + 7 ) << 24 ),
+                              ( e + 8 ) | ( ( e + 9 ) << 8 ) | ( ( e + 10 ) << 16 ) | ( ( e + 11 ) << 24 ),
+                              ( e + 12 ) | ( ( e + 13 ) << 8 ) | ( ( e + 14 ) << 16 ) | ( ( e + 15 ) << 24 ) );
     }
     __syncthreads();
     const uint32_t end = starts[t + 1];
@@ -610,15 +657,17 @@ k_mtf( BlockMeta* __restrict__       meta,
     unsigned long long count = 0;
     {
         uint32_t runPos = 0, hh = 0;
+        SymStream stream;
+        stream.init( sym, begin );
         for ( uint32_t i = begin; i < end; ++i ) {
-            const uint32_t s = sym[i];
+            const uint32_t s = stream.get( i );
             if ( s <= 1 ) {
                 if ( runPos == 0 ) { runPos = 1; hh = 0; }
                 hh += runPos << s;
                 runPos <<= 1;
             } else {
                 if ( runPos != 0 ) { count += hh; runPos = 0; }
-                mtf_lane_move( lists, t, s - 1 );
+                mtf_lane_move( mine, s - 1 );
                 ++count;
             }
         }
@@ -638,18 +687,14 @@ k_mtf( BlockMeta* __restrict__       meta,
         total += waveTotals[w];
     }
 
-    /* ---- compose the chunk permutations in order: slot c receives the list valid at the start of chunk c ---- */
+    /* ---- compose the chunk permutations in order: lane c's list becomes the list valid at the start of chunk c ---- */
     for ( uint32_t c = 0; c < MTF_THREADS; ++c ) {
-        const uint32_t j0 = t, j1 = t + 128;
-        const uint32_t p0 = ( lists[( j0 >> 2 ) * MTF_THREADS + c] >> ( 8 * ( j0 & 3 ) ) ) & 0xFFu;
-        const uint32_t p1 = ( lists[( j1 >> 2 ) * MTF_THREADS + c] >> ( 8 * ( j1 & 3 ) ) ) & 0xFFu;
-        const uint8_t v0 = cur[p0], v1 = cur[p1];
-        const uint8_t o0 = cur[j0], o1 = cur[j1];
+        uint8_t* const slotC = listBytes + c * MTF_LANE_STRIDE;
+        const uint8_t v = cur[slotC[t]];   /* entry t of the list after chunk c = old entry at the permuted position */
+        const uint8_t o = cur[t];
         __syncthreads();
-        reinterpret_cast<uint8_t*>( &lists[( j0 >> 2 ) * MTF_THREADS + c] )[j0 & 3] = o0;
-        reinterpret_cast<uint8_t*>( &lists[( j1 >> 2 ) * MTF_THREADS + c] )[j1 & 3] = o1;
-        cur[j0] = v0;
-        cur[j1] = v1;
+        slotC[t] = o;
+        cur[t] = v;
         __syncthreads();
     }
 
@@ -658,8 +703,10 @@ k_mtf( BlockMeta* __restrict__       meta,
         ByteSink sink{ L, prefix, 0, 0 };
         uint32_t runPos = 0, hh = 0;
         uint32_t err = 0;
+        SymStream stream;
+        stream.init( sym, begin );
         for ( uint32_t i = begin; i < end && err == 0; ++i ) {
-            const uint32_t s = sym[i];
+            const uint32_t s = stream.get( i );
             if ( s <= 1 ) {
                 if ( runPos == 0 ) { runPos = 1; hh = 0; }
                 hh += runPos << s;
@@ -669,17 +716,17 @@ k_mtf( BlockMeta* __restrict__       meta,
             if ( runPos != 0 ) {
                 runPos = 0;
                 if ( sink.o + hh > MAX_N ) { err = ST_RUN_OVERFLOW; break; }
-                sink.fill( lists[t] & 0xFFu, hh );
+                sink.fill( reinterpret_cast<const uint8_t*>( mine )[0], hh );
             }
             if ( sink.o >= MAX_N ) { err = ST_DATA_OVERFLOW; break; }
-            sink.put( mtf_lane_move( lists, t, s - 1 ) );
+            sink.put( mtf_lane_move( mine, s - 1 ) );
         }
         /* a run that is still open where the Huffman stage FAILED is never flushed by the reference */
         if ( err == 0 && runPos != 0 && ( end < n || hm.status == ST_OK ) ) {
             if ( sink.o + hh > MAX_N ) {
                 err = ST_RUN_OVERFLOW;
             } else {
-                sink.fill( lists[t] & 0xFFu, hh );
+                sink.fill( reinterpret_cast<const uint8_t*>( mine )[0], hh );
             }
         }
         sink.flush();
