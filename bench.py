@@ -170,6 +170,13 @@ def main():
     dec = m.Decoder(device=device_index, max_batch_blocks=n_blocks)
     dec.set_input_device(d_in.data_ptr(), len(enc), keepalive=d_in)
 
+    # block offsets: the GPU magic scan over the resident input must find exactly the blocks the file was built from
+    dec.find_magic()
+    t_scan = time.perf_counter()
+    gpu_offsets = dec.find_magic()
+    scan_ms = (time.perf_counter() - t_scan) * 1e3
+    assert gpu_offsets == offsets, "GPU magic scan disagrees with the block offsets of the workload"
+
     gather_buf = None
     expected = meta["decoded_bytes"]
 
@@ -260,7 +267,9 @@ def main():
                        "decoded_bytes_per_gpu": expected, "ratio": round(expected / len(enc), 3),
                        "parallelism": f"block queue sharded over {world} GPU(s)"
                                       + ("" if world == 1 or args.no_gather else ", RCCL gather of decoded extents to rank 0"),
-                       "input_resident_in_hbm": True, "output_left_in_hbm": True},
+                       "input_resident_in_hbm": True, "output_left_in_hbm": True,
+                       "block_offsets": "known before the timed region (index / finder thread); the same offsets from the "
+                                        "GPU magic scan k_find_magic take %.2f ms (not part of a step)" % scan_ms},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_step": int(alg_bytes), "io_floor_bytes_per_step": int(io_floor),

@@ -154,6 +154,12 @@ int mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* ctx, uint32_t index, int stage,
 uint64_t mi355x_bz2_find_magic( const uint8_t* bytes, uint64_t size, uint64_t magic48,
                                 uint64_t* bit_offsets, uint64_t capacity, uint32_t threads );
 
+/* The same scan on the GPU over the input made resident with mi355x_bz2_set_input_* (ascending offsets; at most
+ * `capacity` are written, *n_found = number of matches).  At GPU decode rates the host scan would otherwise be the
+ * critical path. */
+int mi355x_bz2_find_magic_device( mi355x_bz2_ctx* ctx, uint64_t magic48, uint64_t* bit_offsets, uint64_t capacity,
+                                  uint64_t* n_found );
+
 /* bzip2::readBzip2Header (bzip2.hpp:114-142) at a byte-aligned bit offset: returns level 1..9, or 0 if invalid. */
 int mi355x_bz2_read_stream_header( const uint8_t* bytes, uint64_t size, uint64_t bit_offset );
 

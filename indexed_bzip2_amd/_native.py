@@ -86,6 +86,7 @@ SYMBOLS = [
     ("mi355x_bz2_debug_copy_stage", ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_int, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_find_magic", ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _u64p,
                                                  ctypes.c_uint64, ctypes.c_uint32]),
+    ("mi355x_bz2_find_magic_device", ctypes.c_int, [_vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, _u64p]),
     ("mi355x_bz2_read_stream_header", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
     ("mi355x_bz2_reader_open_path", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
     ("mi355x_bz2_reader_open_fd", ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
@@ -193,6 +194,14 @@ class Decoder:
         self._check(lib().mi355x_bz2_decode_batch(self._h, offs, n, res, ctypes.byref(total)))
         self.last_results = [res[i].as_dict() for i in range(n)]
         return self.last_results, total.value
+
+    def find_magic(self, magic: int = MAGIC_BLOCK):
+        """Magic-bit scan of the resident input on the GPU (k_find_magic)."""
+        n = ctypes.c_uint64()
+        self._check(lib().mi355x_bz2_find_magic_device(self._h, magic, None, 0, ctypes.byref(n)))
+        arr = (ctypes.c_uint64 * max(1, n.value))()
+        self._check(lib().mi355x_bz2_find_magic_device(self._h, magic, arr, n.value, ctypes.byref(n)))
+        return list(arr[:n.value])
 
     def output_device_ptr(self) -> int:
         return lib().mi355x_bz2_output_device(self._h) or 0

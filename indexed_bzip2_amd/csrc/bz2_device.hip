@@ -533,6 +533,60 @@ mi355x_bz2_stream( const mi355x_bz2_ctx* c )
 }
 
 int
+mi355x_bz2_find_magic_device( mi355x_bz2_ctx* c, uint64_t magic48, uint64_t* bitOffsets, uint64_t capacity,
+                              uint64_t* nFound )
+{
+    if ( c == nullptr || nFound == nullptr || ( capacity > 0 && bitOffsets == nullptr ) ) {
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    const std::scoped_lock lock( c->mutex );
+    *nFound = 0;
+    if ( c->dIn == nullptr ) {
+        c->lastError = "no input set";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    if ( c->inSize < 6 ) return MI355X_BZ2_OK;
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    constexpr uint32_t CAP = 1u << 20;
+    uint64_t* dFound = nullptr;
+    uint32_t* dCounter = nullptr;
+    HIP_TRY( c, hipMalloc( &dFound, (size_t)CAP * sizeof( uint64_t ) ) );
+    if ( hipMalloc( &dCounter, sizeof( uint32_t ) ) != hipSuccess ) {
+        (void)hipFree( dFound );
+        return MI355X_BZ2_ERR_DEVICE;
+    }
+    int rc = MI355X_BZ2_OK;
+    uint32_t count = 0;
+    std::vector<uint64_t> host;
+    do {
+        if ( hipMemsetAsync( dCounter, 0, sizeof( uint32_t ), c->stream ) != hipSuccess ) { rc = MI355X_BZ2_ERR_DEVICE; break; }
+        hipLaunchKernelGGL( k_find_magic, dim3( 4096 ), dim3( 256 ), 0, c->stream,
+                            reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize * 8, magic48 & 0xFFFFFFFFFFFFULL,
+                            dFound, CAP, dCounter );
+        if ( hipMemcpyAsync( &count, dCounter, sizeof( uint32_t ), hipMemcpyDeviceToHost, c->stream ) != hipSuccess
+             || hipStreamSynchronize( c->stream ) != hipSuccess ) { rc = MI355X_BZ2_ERR_DEVICE; break; }
+        const uint32_t stored = std::min( count, CAP );
+        host.resize( stored );
+        if ( stored > 0
+             && hipMemcpy( host.data(), dFound, (size_t)stored * sizeof( uint64_t ), hipMemcpyDeviceToHost ) != hipSuccess ) {
+            rc = MI355X_BZ2_ERR_DEVICE;
+            break;
+        }
+    } while ( false );
+    (void)hipFree( dFound );
+    (void)hipFree( dCounter );
+    if ( rc != MI355X_BZ2_OK ) {
+        c->lastError = "k_find_magic failed";
+        return rc;
+    }
+    if ( count > CAP ) return MI355X_BZ2_ERR_OUTPUT_CAPACITY;
+    std::sort( host.begin(), host.end() );
+    *nFound = host.size();
+    for ( uint64_t i = 0; i < host.size() && i < capacity; ++i ) bitOffsets[i] = host[i];
+    return MI355X_BZ2_OK;
+}
+
+int
 mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* c, uint32_t index, int stage, void* hostDst, uint64_t capacity )
 {
     if ( c == nullptr || hostDst == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;

@@ -162,6 +162,35 @@ struct BitRd
     }
 };
 
+/* -------------------------------------------------------------------------------------------------------------
+ * k_find_magic: every bit offset of a 48-bit pattern in the resident input (the host form is
+ * mi355x_bz2_find_magic = BitStringFinder<48>, src/core/BitStringFinder.hpp:158-285).  One thread per 32 start
+ * positions: three big-endian words give the 80 bits that the 32 candidate windows of a word need.  Matches are
+ * rare (one per block), so they are appended through a single atomic counter and sorted on the host.
+ * ------------------------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__( 256 ) void
+k_find_magic( const uint32_t* __restrict__ words, uint64_t size_bits, uint64_t magic48,
+              uint64_t* __restrict__ found, uint32_t capacity, uint32_t* __restrict__ counter )
+{
+    const uint64_t nStartWords = ( size_bits + 31 ) >> 5;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for ( uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nStartWords; w += stride ) {
+        const uint64_t hi = ( (uint64_t)words[w] << 32 ) | words[w + 1];   /* input copy is zero padded */
+        const uint64_t lo = (uint64_t)words[w + 2] << 32;
+#pragma unroll 4
+        for ( uint32_t s = 0; s < 32; ++s ) {
+            const uint64_t window = s == 0 ? hi : ( ( hi << s ) | ( lo >> ( 64 - s ) ) );
+            if ( ( window >> 16 ) == magic48 ) {
+                const uint64_t offset = w * 32 + s;
+                if ( offset + 48 <= size_bits ) {
+                    const uint32_t slot = atomicAdd( counter, 1u );
+                    if ( slot < capacity ) found[slot] = offset;
+                }
+            }
+        }
+    }
+}
+
 /** Lanes whose `key` (low `bits` bits) equals this lane's, restricted to `valid` lanes. */
 __device__ __forceinline__ uint64_t
 match_any( uint32_t key, int bits, bool valid )

@@ -75,6 +75,23 @@ def test_silesia_style_slice(native, oracle, dec):
     assert oracle.decode_file(enc)[0] == 0
 
 
+def test_gpu_magic_scan(native, oracle, dec):
+    """k_find_magic against the oracle / the known answers of src/tests/core/testBitStringFinder.cpp:119-146."""
+    M = bytes([0x31, 0x41, 0x59, 0x26, 0x53, 0x59])
+    cases = [M, b"\0" + M, b"\0\0\0\0" + M + b"\0\0", bytes([0x18, 0xA0, 0xAC, 0x93, 0x29, 0xAC, 0x80]),
+             bytes([0x00, 0x62, 0x82, 0xB2, 0x4C, 0xA6, 0xB2]), bytes([0x31, 0x41, 0x59, 0x26, 0x53, 0x58]), M[:5] + b"\0" * 9]
+    base = b"\0\0\0\0" + M + b"\0\0"
+    for gap in (1, 100, 123, 1024, 4095, 4096, 28 * 1024, 1 << 20):
+        cases.append(base + b"\0" * gap + M)
+    for name in fixture_names():
+        cases.append(read_fixture(name)[0])
+    cases.append(datagen.multistream([datagen.text_like(250_000, 31), datagen.random_bytes(150_000, 32)], 1))
+    for data in cases:
+        dec.set_input(data)
+        for magic in (oracle.MAGIC_BLOCK, oracle.MAGIC_EOS):
+            assert dec.find_magic(magic) == oracle.find_magic(data, magic), (len(data), hex(magic))
+
+
 def test_multistream(native, oracle, dec):
     parts = [datagen.text_like(250_000, 31), datagen.random_bytes(150_000, 32), b"", b"x", datagen.runs(99_999, 33)]
     enc = datagen.multistream(parts, 1)
