@@ -39,7 +39,7 @@ def log(*a):
 def build_workload(total_bytes, base_bytes, cache_dir, rank, world, barrier):
     """Rank 0 builds (or finds cached) the .bz2 file; everyone loads it."""
     import numpy as np
-    key = f"silesia_like-{base_bytes}-x{total_bytes}-l9-v2"
+    key = f"silesia_like-{base_bytes}-x{total_bytes}-l9-v3"
     path = os.path.join(cache_dir, key + ".bz2")
     meta_path = path + ".json"
     if rank == 0 and not (os.path.exists(path) and os.path.exists(meta_path)):
@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--total-bytes", type=int, default=2 * 1024**3)
-    ap.add_argument("--base-bytes", type=int, default=212_000_000)
+    ap.add_argument("--base-bytes", type=int, default=214_748_364)   # x10 = 2 GiB - 8 bytes
     ap.add_argument("--cache-dir", default=os.environ.get("BZ2_BENCH_CACHE", "/tmp/indexed_bzip2_amd_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
