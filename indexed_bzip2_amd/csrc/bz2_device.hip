@@ -24,11 +24,16 @@
 
 using namespace bz2gpu;
 
+constexpr uint32_t MAX_CHUNKS = 3;          /* groups of cheap blocks; one more stream than hardware queues (4 by
+                                               default) would serialize two groups */
+constexpr int MAX_GROUPS = MAX_CHUNKS + 1;   /* + the expensive group */
+
 struct mi355x_bz2_ctx
 {
     int device{ 0 };
     uint32_t flags{ 0 };
     hipStream_t stream{ nullptr };
+    hipStream_t gstream[MAX_GROUPS]{};   /* gstream[0] == stream; higher groups = more expensive blocks, higher priority */
     std::string lastError;
     std::mutex mutex;
 
@@ -54,9 +59,10 @@ struct mi355x_bz2_ctx
     uint32_t* dSegLen{ nullptr };
     uint32_t* dSegSucc{ nullptr };
     uint32_t* dSegOff{ nullptr };
-    WalkPlan* dPlan{ nullptr };
-    uint32_t* dWalkBlk{ nullptr };
+    WalkPlan* dPlan{ nullptr };       /* [MAX_GROUPS]: one per group */
+    uint32_t* dWalkBlk{ nullptr };    /* [MAX_GROUPS][cap + 16] */
     uint32_t* dWalkPre{ nullptr };
+    uint32_t* hSlotOf{ nullptr };     /* pinned: original index -> slot */
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
 
@@ -67,7 +73,9 @@ struct mi355x_bz2_ctx
     uint32_t lastBlocks{ 0 };
 
     CrcConsts crc{};
-    hipEvent_t ev[2 * MI355X_BZ2_MAX_KERNELS]{};
+    hipEvent_t ev[MAX_GROUPS][2 * MI355X_BZ2_MAX_KERNELS]{};   /* [group][2 * kernel + {start, end}] */
+    hipEvent_t evStep[3]{};                                     /* step start, inputs uploaded, step end */
+    hipEvent_t evGroupDone[MAX_GROUPS]{};
     uint32_t nKernels{ 0 };
     mi355x_bz2_timings timings{};
 };
@@ -125,6 +133,7 @@ freeScratch( mi355x_bz2_ctx* c )
     (void)hipFree( c->dOffsets ); c->dOffsets = nullptr;
     (void)hipFree( c->dOrder ); c->dOrder = nullptr;
     (void)hipHostFree( c->hOrder ); c->hOrder = nullptr;
+    (void)hipHostFree( c->hSlotOf ); c->hSlotOf = nullptr;
     (void)hipFree( c->dMeta ); c->dMeta = nullptr;
     (void)hipFree( c->dSel ); c->dSel = nullptr;
     (void)hipFree( c->dSym ); c->dSym = nullptr;
@@ -167,9 +176,10 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     HIP_TRY( c, hipMalloc( &c->dSegLen, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dSegSucc, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dSegOff, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dPlan, sizeof( WalkPlan ) ) );
-    HIP_TRY( c, hipMalloc( &c->dWalkBlk, ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dWalkPre, ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dPlan, MAX_GROUPS * sizeof( WalkPlan ) ) );
+    HIP_TRY( c, hipMalloc( &c->dWalkBlk, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dWalkPre, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipHostMalloc( &c->hSlotOf, (size_t)cap * sizeof( uint32_t ), hipHostMallocDefault ) );
     HIP_TRY( c, hipHostMalloc( &c->hMeta, (size_t)cap * sizeof( BlockMeta ), hipHostMallocDefault ) );
     HIP_TRY( c, hipHostMalloc( &c->hOffsets, (size_t)cap * sizeof( uint64_t ), hipHostMallocDefault ) );
     c->capacity = cap;
@@ -202,11 +212,11 @@ static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
 }  // namespace
 
 /* record an event pair around one launch so that every kernel gets its own device duration */
-#define TIMED_LAUNCH( ctx, index, ... )                                           \
-    do {                                                                          \
-        HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[2 * ( index )], ( ctx )->stream ) );     \
-        hipLaunchKernelGGL( __VA_ARGS__ );                                        \
-        HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[2 * ( index ) + 1], ( ctx )->stream ) ); \
+#define TIMED_LAUNCH( ctx, group, queue, index, ... )                                      \
+    do {                                                                                   \
+        HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[group][2 * ( index )], queue ) );        \
+        hipLaunchKernelGGL( __VA_ARGS__ );                                                 \
+        HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[group][2 * ( index ) + 1], queue ) );    \
     } while ( 0 )
 
 extern "C" {
@@ -282,7 +292,34 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
         delete c;
         return MI355X_BZ2_ERR_DEVICE;
     }
-    for ( auto& e : c->ev ) {
+    c->gstream[0] = c->stream;
+    {
+        int leastPriority = 0, greatestPriority = 0;   /* numerically lower = higher priority */
+        (void)hipDeviceGetStreamPriorityRange( &leastPriority, &greatestPriority );
+        for ( int g = 1; g < MAX_GROUPS; ++g ) {
+            /* gstream[MAX_GROUPS - 1] serves the expensive group: its k_huff is the longest chain of a batch */
+            const int priority = g == MAX_GROUPS - 1 ? greatestPriority : ( leastPriority + greatestPriority ) / 2;
+            if ( hipStreamCreateWithPriority( &c->gstream[g], hipStreamNonBlocking, priority ) != hipSuccess ) {
+                delete c;
+                return MI355X_BZ2_ERR_DEVICE;
+            }
+        }
+    }
+    for ( auto& e : c->evGroupDone ) {
+        if ( hipEventCreate( &e ) != hipSuccess ) {
+            delete c;
+            return MI355X_BZ2_ERR_DEVICE;
+        }
+    }
+    for ( auto& group : c->ev ) {
+        for ( auto& e : group ) {
+            if ( hipEventCreate( &e ) != hipSuccess ) {
+                delete c;
+                return MI355X_BZ2_ERR_DEVICE;
+            }
+        }
+    }
+    for ( auto& e : c->evStep ) {
         if ( hipEventCreate( &e ) != hipSuccess ) {
             delete c;
             return MI355X_BZ2_ERR_DEVICE;
@@ -306,13 +343,27 @@ mi355x_bz2_destroy( mi355x_bz2_ctx* c )
     if ( c == nullptr ) return;
     (void)hipSetDevice( c->device );
     if ( c->stream ) (void)hipStreamSynchronize( c->stream );
+    for ( int g = 1; g < MAX_GROUPS; ++g ) {
+        if ( c->gstream[g] ) (void)hipStreamSynchronize( c->gstream[g] );
+    }
     freeScratch( c );
     (void)hipFree( c->dInOwned );
     (void)hipFree( c->dOut );
-    for ( auto& e : c->ev ) {
+    for ( auto& group : c->ev ) {
+        for ( auto& e : group ) {
+            if ( e ) (void)hipEventDestroy( e );
+        }
+    }
+    for ( auto& e : c->evStep ) {
         if ( e ) (void)hipEventDestroy( e );
     }
     if ( c->stream ) (void)hipStreamDestroy( c->stream );
+    for ( int g = 1; g < MAX_GROUPS; ++g ) {
+        if ( c->gstream[g] ) (void)hipStreamDestroy( c->gstream[g] );
+    }
+    for ( auto& e : c->evGroupDone ) {
+        if ( e ) (void)hipEventDestroy( e );
+    }
     delete c;
 }
 
@@ -400,71 +451,164 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     int rc = ensureScratch( c, n );
     if ( rc != MI355X_BZ2_OK ) return rc;
 
-    std::memcpy( c->hOffsets, offsets, (size_t)n * sizeof( uint64_t ) );
-    HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
+    /* ---- plan: cost estimate, groups, slots, work order --------------------------------------------------------
+     * cost = estimated compressed size (distance to the next requested offset, or to the end of the input).
+     * k_huff is one serial chain per block: a launch lasts as long as its LARGEST block, and its waves are bound by
+     * the scalar unit (one per CU), so they slow each other down beyond a few waves per CU.  Everything behind it
+     * (MTF, BWT, walk, RLE, CRC) is throughput work of about the same size for every block.  The batch is therefore
+     * cut into groups, each with its own HIP stream, such that the throughput work starts early and never runs dry:
+     *   - the "expensive" group: blocks above 45 % of the largest cost, if they are a minority (incompressible blocks
+     *     among text).  Its k_huff starts at once and runs beside everything else on a high-priority stream.
+     *   - the other blocks, sorted by cost, in up to MAX_CHUNKS chunks of growing size.  All k_huff launches start
+     *     together; a chunk of cheap blocks is through k_huff early, and its MTF .. RLE kernels run while the later
+     *     chunks are still in k_huff.  (Chaining the k_huff launches instead was measured to be slower: a k_huff wave
+     *     is latency bound, co-resident waves barely slow it down.)
+     * Inside a group the stage-1 kernels start their largest blocks first (LPT).
+     * Slots: group g occupies slots [groupFirst[g], +groupCount[g]) of every per-block buffer; results are mapped
+     * back to input order. */
+    std::vector<uint64_t> cost( n );
     {
-        /* Work order for the latency-bound stage-1 kernels: estimated compressed size (distance to the next requested
-         * offset, or to the end of the input) descending.  Purely a scheduling hint; results are indexed by block. */
         std::vector<uint32_t> byOffset( n );
         for ( uint32_t i = 0; i < n; ++i ) byOffset[i] = i;
         std::sort( byOffset.begin(), byOffset.end(), [&] ( uint32_t a, uint32_t b ) { return offsets[a] < offsets[b]; } );
-        std::vector<uint64_t> cost( n );
         for ( uint32_t k = 0; k < n; ++k ) {
             const uint64_t next = k + 1 < n ? offsets[byOffset[k + 1]] : c->inSize * 8;
             const uint64_t cur = offsets[byOffset[k]];
             cost[byOffset[k]] = next > cur ? next - cur : 0;
         }
-        for ( uint32_t i = 0; i < n; ++i ) c->hOrder[i] = i;
-        std::stable_sort( c->hOrder, c->hOrder + n, [&] ( uint32_t a, uint32_t b ) { return cost[a] > cost[b]; } );
-        HIP_TRY( c, hipMemcpyAsync( c->dOrder, c->hOrder, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
+    }
+    uint64_t maxCost = 0;
+    for ( const auto v : cost ) maxCost = std::max( maxCost, v );
+    const char* noSplit = std::getenv( "MI355X_BZ2_NO_SPLIT" );
+    const bool split = n >= 64 && !( noSplit != nullptr && noSplit[0] == '1' );
+
+    std::vector<uint32_t> ascending( n );   /* block indices by increasing cost */
+    for ( uint32_t i = 0; i < n; ++i ) ascending[i] = i;
+    std::stable_sort( ascending.begin(), ascending.end(), [&] ( uint32_t a, uint32_t b ) { return cost[a] < cost[b]; } );
+
+    uint32_t nExpensive = 0;
+    if ( split ) {
+        while ( nExpensive < n && cost[ascending[n - 1 - nExpensive]] * 100 > maxCost * 45 ) ++nExpensive;
+        if ( nExpensive < 16 || (uint64_t)nExpensive * 100 > (uint64_t)n * 35 ) nExpensive = 0;
+    }
+    const uint32_t nCheap = n - nExpensive;
+    uint32_t nChunks = 1;
+    if ( split ) {
+        /* measured on MI355X: a lone k_huff wave takes about 5.5 ns per compressed bit; the kernels behind k_huff
+         * together about 0.04 ms per block when the GPU is full */
+        const double huffMs = (double)cost[ascending[nCheap - 1]] * 5.5e-6;
+        const double restMs = (double)nCheap * 0.04;
+        const double ratio = restMs / std::max( huffMs, 1e-3 );
+        nChunks = (uint32_t)std::min<double>( { ratio, (double)MAX_CHUNKS, (double)( nCheap / 128 ) } );
+        nChunks = std::max( nChunks, 1u );
+        if ( const char* forced = std::getenv( "MI355X_BZ2_CHUNKS" ); forced != nullptr && std::atoi( forced ) > 0 ) {
+            nChunks = std::min<uint32_t>( (uint32_t)std::atoi( forced ), MAX_CHUNKS );
+        }
+    }
+    const int nGroups = (int)nChunks + ( nExpensive > 0 ? 1 : 0 );
+    const int expensiveGroup = nExpensive > 0 ? (int)nChunks : -1;
+    uint32_t groupCount[MAX_GROUPS] = {};
+    uint32_t groupFirst[MAX_GROUPS] = {};
+    {
+        /* chunk g ends at rank nCheap * (g + 1)(g + 2) / (K (K + 1)): 1/3, 1 for two chunks; 1/6, 1/2, 1 for three --
+         * a small first chunk gets the throughput kernels going early, the later ones keep them fed */
+        uint32_t begin = 0;
+        for ( uint32_t g = 0; g < nChunks; ++g ) {
+            const uint32_t end = (uint32_t)( (uint64_t)nCheap * ( g + 1 ) * ( g + 2 ) / ( (uint64_t)nChunks * ( nChunks + 1 ) ) );
+            groupCount[g] = end - begin;
+            begin = end;
+        }
+    }
+    if ( expensiveGroup >= 0 ) groupCount[expensiveGroup] = nExpensive;
+    for ( int g = 1; g < nGroups; ++g ) groupFirst[g] = groupFirst[g - 1] + groupCount[g - 1];
+    /* slot = rank by cost: group g = ranks [groupFirst[g], +groupCount[g]); LPT order inside the group = descending */
+    for ( uint32_t rank = 0; rank < n; ++rank ) {
+        c->hSlotOf[ascending[rank]] = rank;
+        c->hOffsets[rank] = offsets[ascending[rank]];
+    }
+    for ( int g = 0; g < nGroups; ++g ) {
+        uint32_t* order = c->hOrder + groupFirst[g];
+        for ( uint32_t k = 0; k < groupCount[g]; ++k ) order[k] = groupCount[g] - 1 - k;   /* group-relative slot */
+    }
+    HIP_TRY( c, hipEventRecord( c->evStep[0], c->stream ) );
+    HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
+    HIP_TRY( c, hipMemcpyAsync( c->dOrder, c->hOrder, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
+    HIP_TRY( c, hipEventRecord( c->evStep[1], c->stream ) );
+    auto streamOf = [&] ( int g ) { return g == expensiveGroup ? c->gstream[MAX_GROUPS - 1] : c->gstream[g]; };
+    for ( int g = 1; g < nGroups; ++g ) {
+        HIP_TRY( c, hipStreamWaitEvent( streamOf( g ), c->evStep[1], 0 ) );
     }
 
-    {
-        const char* hl = std::getenv( "MI355X_BZ2_HUFF_LDS_PAD" );   /* tuning knob: extra LDS per workgroup lowers occupancy */
-        const uint32_t huffPad = hl != nullptr ? (uint32_t)std::atoi( hl ) : 0u;
-        TIMED_LAUNCH( c, 0, k_huff, dim3( ( n + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), huffPad, c->stream,
-                      reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets, c->dMeta, c->dHmeta, c->dSel,
-                      c->dSym, c->dStb, n, c->dOrder );
-        TIMED_LAUNCH( c, 1, k_mtf, dim3( n ), dim3( MTF_THREADS ), 0, c->stream,
-                      c->dMeta, c->dHmeta, c->dSym, c->dStb, c->dL, n, c->dOrder );
-    }
-    TIMED_LAUNCH( c, 2, k_bwt_build, dim3( n ), dim3( 1024 ), 0, c->stream, c->dMeta, c->dL, c->dTab );
-    {
-        const char* wg = std::getenv( "MI355X_BZ2_WALK_WGS" );   /* tuning knob: workgroups per XCD */
-        const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0 ? (uint32_t)std::atoi( wg ) : WALK_WGS_PER_XCD;
+    const char* wg = std::getenv( "MI355X_BZ2_WALK_WGS" );   /* tuning knob: workgroups per XCD */
+    const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0 ? (uint32_t)std::atoi( wg ) : WALK_WGS_PER_XCD;
+    const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
+    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
+
+    for ( int launch = 0; launch < nGroups; ++launch ) {
+        /* the expensive group is queued first, then the chunks from cheap to less cheap */
+        const int g = expensiveGroup >= 0 ? ( launch == 0 ? expensiveGroup : launch - 1 ) : launch;
+        const uint32_t m = groupCount[g], first = groupFirst[g];
+        hipStream_t q = streamOf( g );
+        BlockMeta* const meta = c->dMeta + first;
+        HuffMeta* const hmeta = c->dHmeta + first;
+        uint8_t* const sel = c->dSel + (size_t)first * SEL_STRIDE;
+        uint16_t* const sym = c->dSym + (size_t)first * SYM_STRIDE;
+        uint8_t* const stb = c->dStb + (size_t)first * 256;
+        uint8_t* const lcol = c->dL + (size_t)first * L_STRIDE;
+        uint32_t* const tab = c->dTab + (size_t)first * TAB_STRIDE;
+        uint8_t* const rbuf = c->dR + (size_t)first * L_STRIDE;
+        uint32_t* const segLen = c->dSegLen + (size_t)first * SEG_STRIDE;
+        uint32_t* const segSucc = c->dSegSucc + (size_t)first * SEG_STRIDE;
+        uint32_t* const segOff = c->dSegOff + (size_t)first * SEG_STRIDE;
+        const uint32_t* const order = c->dOrder + first;
+        WalkPlan* const plan = c->dPlan + g;
+        uint32_t* const walkBlk = c->dWalkBlk + (size_t)g * ( c->capacity + 16 );
+        uint32_t* const walkPre = c->dWalkPre + (size_t)g * ( c->capacity + 16 );
         const dim3 walkGrid( WALK_QUEUES * wgsPerXcd );
-        const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
-        const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
-        TIMED_LAUNCH( c, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, c->stream, c->dMeta, n, c->dPlan, c->dWalkBlk, c->dWalkPre );
-        TIMED_LAUNCH( c, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, c->stream,
-                      c->dMeta, c->dTab, c->dPlan, c->dWalkBlk, c->dWalkPre, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR, walkChunk );
-        TIMED_LAUNCH( c, 4, k_link2, dim3( n ), dim3( LINK_THREADS ), 0, c->stream, c->dMeta, c->dSegLen, c->dSegSucc, c->dSegOff );
-        TIMED_LAUNCH( c, 5, k_walk2<true>, walkGrid, dim3( WALK_THREADS ), 0, c->stream,
-                      c->dMeta, c->dTab, c->dPlan, c->dWalkBlk, c->dWalkPre, c->dSegLen, c->dSegSucc, c->dSegOff, c->dR, walkChunk );
-    }
-    TIMED_LAUNCH( c, 6, k_replicate, dim3( n ), dim3( 256 ), 0, c->stream, c->dMeta, c->dR );
-    TIMED_LAUNCH( c, 7, k_rle<false>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, (uint8_t*)nullptr );
-    HIP_TRY( c, hipGetLastError() );
 
-    /* sizes -> host: output offsets are an exclusive scan of the decoded sizes (ragged, gap-free) */
+        TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), 0, q,
+                      reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
+                      m, order );
+        TIMED_LAUNCH( c, g, q, 1, k_mtf, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+        TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
+        TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
+        TIMED_LAUNCH( c, g, q, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, q,
+                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, segOff, rbuf, walkChunk );
+        TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segOff );
+        TIMED_LAUNCH( c, g, q, 5, k_walk2<true>, walkGrid, dim3( WALK_THREADS ), 0, q,
+                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, segOff, rbuf, walkChunk );
+        TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf );
+        TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );
+        if ( g >= 1 ) {
+            HIP_TRY( c, hipEventRecord( c->evGroupDone[g], q ) );
+        }
+    }
+    HIP_TRY( c, hipGetLastError() );
+    for ( int g = 1; g < nGroups; ++g ) {
+        HIP_TRY( c, hipStreamWaitEvent( c->stream, c->evGroupDone[g], 0 ) );
+    }
+
+    /* sizes -> host: output offsets are an exclusive scan of the decoded sizes IN INPUT ORDER (ragged, gap-free) */
     HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     uint64_t total = 0;
     for ( uint32_t i = 0; i < n; ++i ) {
-        c->hMeta[i].out_off = total;
-        if ( c->hMeta[i].walk_ok ) total += c->hMeta[i].decoded_size;
+        BlockMeta& m = c->hMeta[c->hSlotOf[i]];
+        m.out_off = total;
+        if ( m.walk_ok ) total += m.decoded_size;
     }
     rc = ensureOutput( c, total );
     if ( rc != MI355X_BZ2_OK ) return rc;
     HIP_TRY( c, hipMemcpyAsync( c->dMeta, c->hMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) );
-    TIMED_LAUNCH( c, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
-    TIMED_LAUNCH( c, 9, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
+    TIMED_LAUNCH( c, 0, c->stream, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
+    TIMED_LAUNCH( c, 0, c->stream, 9, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
+    HIP_TRY( c, hipEventRecord( c->evStep[2], c->stream ) );
     HIP_TRY( c, hipGetLastError() );
     HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
 
     for ( uint32_t i = 0; i < n; ++i ) {
-        const BlockMeta& m = c->hMeta[i];
+        const BlockMeta& m = c->hMeta[c->hSlotOf[i]];
         mi355x_bz2_block_result& r = results[i];
         r.encoded_offset_bits = m.enc_off;
         /* set by the reference only after the symbol loop AND the origPtr check (bzip2.hpp:794-806); EOS: header only */
@@ -489,11 +633,29 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     float ms = 0;
     c->timings = {};
     c->timings.n_kernels = N_KERNELS;
-    if ( hipEventElapsedTime( &ms, c->ev[0], c->ev[2 * 9 + 1] ) == hipSuccess ) c->timings.ms_total = ms;   /* k_huff start .. k_crc end */
+    if ( const char* trace = std::getenv( "MI355X_BZ2_TRACE" ); trace != nullptr && trace[0] == '1' ) {
+        /* per-group timeline relative to the step start: [start, end] of every kernel in ms */
+        for ( int g = 0; g < nGroups; ++g ) {
+            std::fprintf( stderr, "[mi355x_bz2] group %d%s (%u blocks):", g, g == expensiveGroup ? " expensive" : "",
+                          groupCount[g] );
+            for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
+                if ( ( k == 8 || k == 9 ) && g >= 1 ) continue;
+                float t0 = 0, t1 = 0;
+                (void)hipEventElapsedTime( &t0, c->evStep[0], c->ev[g][2 * k] );
+                (void)hipEventElapsedTime( &t1, c->evStep[0], c->ev[g][2 * k + 1] );
+                std::fprintf( stderr, " %s[%.1f-%.1f]", KERNEL_NAMES[k], t0, t1 );
+            }
+            std::fprintf( stderr, "\n" );
+        }
+    }
+    if ( hipEventElapsedTime( &ms, c->evStep[0], c->evStep[2] ) == hipSuccess ) c->timings.ms_total = ms;   /* wall */
     for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
-        if ( hipEventElapsedTime( &ms, c->ev[2 * k], c->ev[2 * k + 1] ) == hipSuccess ) {
-            c->timings.ms_kernel[k] = ms;
-            c->timings.ms_kernel_sum += ms;
+        for ( int g = 0; g < nGroups; ++g ) {
+            if ( ( k == 8 || k == 9 ) && g >= 1 ) continue;   /* 8, 9: once for the whole batch */
+            if ( hipEventElapsedTime( &ms, c->ev[g][2 * k], c->ev[g][2 * k + 1] ) == hipSuccess ) {
+                c->timings.ms_kernel[k] += ms;
+                c->timings.ms_kernel_sum += ms;
+            }
         }
     }
     return MI355X_BZ2_OK;
@@ -592,6 +754,7 @@ mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* c, uint32_t index, int stage, void*
     if ( c == nullptr || hostDst == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex );
     if ( index >= c->lastBlocks ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    index = c->hSlotOf[index];   /* per-block buffers are in slot order */
     const uint64_t N = c->hMeta[index].n;
     const void* src = nullptr;
     uint64_t bytes = 0;

@@ -27,6 +27,16 @@ constexpr uint32_t SYM_CAP = 900096;
 constexpr uint32_t MTF_THREADS = 256;      /* lanes (= chunks) per block in k_mtf: one workgroup per block */
 constexpr uint32_t MTF_LANE_STRIDE = 272;  /* bytes between the lists of consecutive lanes: 256 + 16, so that the 16-byte
                                               accesses of the 16 lanes served together fall on 64 distinct banks */
+constexpr uint32_t CHAIN_END = 54;      /* a chain step starts below this bit of the 64-bit window: the 10 start bits of
+                                           an entry then stay inside the window (the asm below spells the number out) */
+/* one branch-free step of the code chain in k_huff; operands as in the asm statements there */
+#define HUFF_CHAIN_STEP \
+    "v_readlane_b32 s96, %[M], %[cur]\n\t" \
+    "s_lshr_b32 %[adv], s96, 10\n\t" \
+    "s_and_b64 s[98:99], s[96:97], 0x3ff\n\t" \
+    "s_lshl_b64 s[98:99], s[98:99], %[cur]\n\t" \
+    "s_or_b64 %[mask], %[mask], s[98:99]\n\t" \
+    "s_add_u32 %[cur], %[cur], %[adv]\n\t"
 constexpr uint32_t HUFF_WAVES = 1;      /* independent blocks (one per wavefront) per k_huff workgroup */
 
 /** Orders LDS traffic between the lanes of ONE wavefront (no s_barrier: the waves of a k_huff workgroup are independent). */
@@ -291,8 +301,10 @@ k_huff( const uint32_t* __restrict__ in_words,
                 uint32_t p = 0, mask = 0;
                 while ( p < (uint32_t)LUT_BITS ) {
                     const uint32_t idx = ( e << p ) & ( ( 1u << LUT_BITS ) - 1u );
-                    const uint32_t len = sh.lut[t][idx] & 31u;
-                    if ( len == 0 || p + len > (uint32_t)LUT_BITS ) break;
+                    const uint32_t single = sh.lut[t][idx] & 0xFFFFu;
+                    const uint32_t len = single & 31u;
+                    /* the end-of-block symbol is never part of a step: the chain stops in front of it */
+                    if ( len == 0 || p + len > (uint32_t)LUT_BITS || ( single >> 5 ) == symbolCount + 1 ) break;
                     mask |= 1u << p;
                     p += len;
                 }
@@ -311,7 +323,7 @@ k_huff( const uint32_t* __restrict__ in_words,
         const uint64_t sizeBits = br.size_bits;
         const uint64_t safeEnd = sizeBits > 256 ? sizeBits - 256 : 0;   /* below this no code can cross the end */
         const uint32_t eob = symbolCount + 1;
-        uint32_t groupLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
+        uint32_t groupLeft = 0, fastLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
         uint32_t limitV = 0;   /* lane l in (LUT_BITS, 20]: left-aligned (20 bit) end of the length-l code range */
         bool finished = false;
 
@@ -336,6 +348,9 @@ k_huff( const uint32_t* __restrict__ in_words,
                 tcur = (uint32_t)( selCur >> ( 8 * ( selIdx & 7u ) ) ) & 0xFFu;
                 ++selIdx;
                 groupLeft = 50;
+                /* windows of this group start below pos + 50 * 20 bits: far enough from the end of the input and of
+                 * the symbol buffer, the whole group may take the fast path */
+                fastLeft = ( pos + 1100 <= safeEnd && cnt + 50 <= SYM_CAP ) ? 50u : 0u;
                 tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
                 limitV = ( lane > (uint32_t)LUT_BITS && lane <= 20 )
                          ? ( ( sh.first[tcur][lane] + sh.count[tcur][lane] ) << ( 20 - lane ) ) : 0u;
@@ -350,23 +365,26 @@ k_huff( const uint32_t* __restrict__ in_words,
             const uint32_t shv = (uint32_t)( pos + lane ) & 31u;
             const uint32_t bits32 = (uint32_t)( ( ( ( (uint64_t)hi << 32 ) | lo ) << shv ) >> 32 );
             const uint32_t E = sh.lut[tcur][bits32 >> ( 32 - LUT_BITS )];
-            const uint32_t Mv = E >> 16;
+            /* chain entries: lanes >= CHAIN_END never start a step (their entry reads as "stop"), which makes a step
+             * at such a position a no-op and lets the first steps run without any branch */
+            const uint32_t Mv = lane < CHAIN_END ? E >> 16 : 0u;
 
-            /* Follow the code chain on the scalar unit.  A position whose code is longer than LUT_BITS is resolved in
-             * place by comparing its 20-bit window against the per-length code range ends held one per lane
-             * (canonical codes: the first length whose range end exceeds the window is the code length;
-             * = decodeLong, HuffmanCodingShortBitsCached.hpp:117-150). */
+            /* Follow the code chain on the scalar unit: e = Mv[cur]; adv = e >> 10; mask |= (e & 0x3ff) << cur;
+             * cur += adv.  An entry with adv == 0 ("stop": long code, end-of-block symbol first, no code, or lane >=
+             * CHAIN_END) leaves cur and mask unchanged, so CHAIN_UNROLL steps are issued back to back without a branch
+             * (a not-taken branch costs 13 cycles, a taken one 21, a SALU op 4.5 on this machine); the loop behind them
+             * finishes windows that need more steps.  s[96:99] are scratch: s96 receives the lane value, s97 is
+             * don't-care (masked by the 64-bit and). */
             uint32_t cur = 0;
             uint64_t mask = 0;
-            uint32_t lenOv = 0;     /* per lane: length of a long code that starts here and is on the chain */
-            bool anyLong = false, invalid = false;
-            for ( ;; ) {
-                /* Hot loop, hand scheduled (9 scalar instructions per step): e = Mv[cur]; adv = e >> 10;
-                 * if adv == 0 leave (long code at cur); mask |= (e & 0x3ff) << cur; cur += adv; repeat while cur < 54.
-                 * s[96:99] are scratch: s96 receives the lane value, s97 is don't-care (masked by the 64-bit and). */
+            {
                 uint32_t adv;
                 asm volatile(
+                    HUFF_CHAIN_STEP HUFF_CHAIN_STEP HUFF_CHAIN_STEP HUFF_CHAIN_STEP
+                    HUFF_CHAIN_STEP HUFF_CHAIN_STEP HUFF_CHAIN_STEP
                     "1:\n\t"
+                    "s_cmp_lt_u32 %[cur], 54\n\t"
+                    "s_cbranch_scc0 2f\n\t"
                     "v_readlane_b32 s96, %[M], %[cur]\n\t"
                     "s_lshr_b32 %[adv], s96, 10\n\t"
                     "s_cbranch_scc0 2f\n\t"
@@ -374,13 +392,48 @@ k_huff( const uint32_t* __restrict__ in_words,
                     "s_lshl_b64 s[98:99], s[98:99], %[cur]\n\t"
                     "s_or_b64 %[mask], %[mask], s[98:99]\n\t"
                     "s_add_u32 %[cur], %[cur], %[adv]\n\t"
-                    "s_cmp_lt_u32 %[cur], 54\n\t"
-                    "s_cbranch_scc1 1b\n\t"
+                    "s_branch 1b\n\t"
                     "2:\n\t"
                     : [cur] "+s"( cur ), [mask] "+s"( mask ), [adv] "=&s"( adv )
                     : [M] "v"( Mv )
                     : "scc", "s96", "s97", "s98", "s99" );
-                if ( adv != 0 ) break;   /* cur >= 54 */
+            }
+            uint32_t mySym = ( E & 0xFFFFu ) >> 5;
+
+            /* Fast path (almost every window): the chain ran to the end of the window and stays inside the current
+             * group.  End-of-block cannot be among the symbols (its entries read as "stop"), the end of the input and
+             * the symbol capacity were checked for the whole group when it was opened. */
+            {
+                const uint32_t nFast = (uint32_t)__popcll( mask );
+                if ( __builtin_expect( ( cur >= CHAIN_END ) & ( nFast <= fastLeft ), 1 ) ) {
+                    if ( __builtin_amdgcn_inverse_ballot_w64( mask ) ) {
+                        const uint32_t slot = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ),
+                                                                         __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, cnt ) );
+                        symOut[slot] = (uint16_t)mySym;
+                    }
+                    cnt += nFast;
+                    nsym += nFast;
+                    groupLeft -= nFast;
+                    fastLeft -= nFast;
+                    pos += cur;
+                    continue;
+                }
+            }
+
+            /* General path.  A stop at cur < CHAIN_END is resolved here: an end-of-block symbol (its short code is in
+             * the single half of the entry) ends the chain; a code longer than LUT_BITS is found by comparing its 20-bit
+             * window against the per-length code range ends held one per lane (canonical codes: the first length whose
+             * range end exceeds the window is the code length; = decodeLong, HuffmanCodingShortBitsCached.hpp:117-150),
+             * after which the chain continues. */
+            uint32_t lenOv = 0;     /* per lane: length of a long code that starts here and is on the chain */
+            bool anyLong = false, invalid = false;
+            while ( cur < CHAIN_END ) {
+                const uint32_t shortLen = (uint32_t)__builtin_amdgcn_readlane( (int)( E & 31u ), cur );
+                if ( shortLen != 0 ) {   /* end-of-block symbol starts here */
+                    mask |= 1ull << cur;
+                    cur += shortLen;
+                    break;
+                }
                 if ( cur > 44 ) break;   /* a long code here could end past bit 64: leave it to the next window, so that
                                             a window never advances by more than 64 bits (the prefetched words cover 95) */
                 const uint32_t v20 = (uint32_t)__builtin_amdgcn_readlane( bits32, cur ) >> 12;   /* readlane returns int */
@@ -391,13 +444,28 @@ k_huff( const uint32_t* __restrict__ in_words,
                 anyLong = true;
                 mask |= 1ull << cur;
                 cur += l;
-                if ( cur >= 54 ) break;
+                uint32_t adv;
+                asm volatile(
+                    "1:\n\t"
+                    "s_cmp_lt_u32 %[cur], 54\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "v_readlane_b32 s96, %[M], %[cur]\n\t"
+                    "s_lshr_b32 %[adv], s96, 10\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "s_and_b64 s[98:99], s[96:97], 0x3ff\n\t"
+                    "s_lshl_b64 s[98:99], s[98:99], %[cur]\n\t"
+                    "s_or_b64 %[mask], %[mask], s[98:99]\n\t"
+                    "s_add_u32 %[cur], %[cur], %[adv]\n\t"
+                    "s_branch 1b\n\t"
+                    "2:\n\t"
+                    : [cur] "+s"( cur ), [mask] "+s"( mask ), [adv] "=&s"( adv )
+                    : [M] "v"( Mv )
+                    : "scc", "s96", "s97", "s98", "s99" );
             }
 
             uint32_t nSyms = (uint32_t)__popcll( mask );
             uint32_t consumed = cur;
             uint32_t myLen = E & 31u;
-            uint32_t mySym = ( E & 0xFFFFu ) >> 5;
             if ( anyLong ) {
                 if ( lenOv != 0 ) {
                     const uint32_t code = bits32 >> ( 32 - lenOv );
@@ -451,6 +519,7 @@ k_huff( const uint32_t* __restrict__ in_words,
             cnt += nSyms;
             nsym += nSyms;
             groupLeft -= nSyms;
+            fastLeft = fastLeft != 0 ? groupLeft : 0u;
             if ( status != ST_OK ) break;
             pos += consumed;
             if ( finished ) { ++nsym; break; }
