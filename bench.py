@@ -229,10 +229,12 @@ def main():
     t0 = time.perf_counter()
     ksum = {}
     ktotal = 0.0
+    gpu_ms = 0.0
     for _ in range(args.steps):
         step()
         t = dec.timings()
         ktotal += t["ms_kernel_sum"]
+        gpu_ms += t["ms_total"]
         for k, v in t["kernels"].items():
             ksum[k] = ksum.get(k, 0.0) + v
     torch.cuda.synchronize()
@@ -249,7 +251,10 @@ def main():
         kavg = {k: v / steps for k, v in ksum.items()}
         dom = max(kavg, key=kavg.get)
         kernel_ms = ktotal / steps
-        achieved = alg_bytes / (kernel_ms / 1e3) / 1e9
+        # one "launch" = the kernel pipeline of one decode_batch: its groups of blocks run on several HIP streams and
+        # overlap, so the duration is taken between HIP events before the first and after the last kernel of the step
+        pipeline_ms = gpu_ms / steps
+        achieved = alg_bytes / (pipeline_ms / 1e3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -273,9 +278,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_step": int(alg_bytes), "io_floor_bytes_per_step": int(io_floor),
-                         "definition": "sum over blocks of (C + 10 N + D) / sum of per-kernel HIP-event durations "
-                                       "of one step (rank 0)",
-                         "kernel_ms_per_step": round(kernel_ms, 3), "dominant_kernel": dom,
+                         "definition": "sum over blocks of (C + 10 N + D) / duration of the kernel pipeline of one step, "
+                                       "HIP events on the launch streams from before the first to after the last kernel "
+                                       "(rank 0); kernels_ms are per-kernel event durations summed over the block groups, "
+                                       "which run on separate streams and overlap",
+                         "pipeline_ms_per_step": round(pipeline_ms, 3),
+                         "kernel_ms_sum_per_step": round(kernel_ms, 3), "dominant_kernel": dom,
                          "kernels_ms": {k: round(v, 3) for k, v in kavg.items()}},
         }
         if not args.no_cpu_baseline:

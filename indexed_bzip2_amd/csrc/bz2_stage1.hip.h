@@ -37,6 +37,7 @@ constexpr uint32_t CHAIN_END = 54;      /* a chain step starts below this bit of
     "s_lshl_b64 s[98:99], s[98:99], %[cur]\n\t" \
     "s_or_b64 %[mask], %[mask], s[98:99]\n\t" \
     "s_add_u32 %[cur], %[cur], %[adv]\n\t"
+constexpr uint32_t HUFF_RING = 1024;    /* symbols in the LDS staging ring of k_huff; flushed in halves */
 constexpr uint32_t HUFF_WAVES = 1;      /* independent blocks (one per wavefront) per k_huff workgroup */
 
 /** Orders LDS traffic between the lanes of ONE wavefront (no s_barrier: the waves of a k_huff workgroup are independent). */
@@ -65,11 +66,28 @@ struct HuffShared
     uint32_t count[6][24];
     uint32_t offs[6][24];
     uint32_t running[24];
-    uint8_t  lens[6][264];
+    uint32_t limit[6][24];            /* [t][l], l in (LUT_BITS, 20]: (first + count) << (20 - l), else 0 */
+    union alignas( 16 ) {
+        uint8_t  lens[6][264];          /* code lengths, only while the tables are built */
+        uint16_t ring[HUFF_RING];       /* decoded symbols on their way to memory, only in the symbol loop */
+    };
     uint16_t bitmap[16];
     uint8_t  sym_to_byte[256];
     uint32_t minmax[6];
 };
+
+/** Symbols [base, base + count) of the staging ring -> memory, eight per lane (one 16-byte store).  Storing every
+ * window's few symbols straight to memory would put a store in front of every wait for the prefetched stream words:
+ * s_waitcnt vmcnt counts loads and stores together, so each window would sit out a store acknowledge. */
+__device__ __forceinline__ void
+huff_flush( const HuffShared& sh, uint16_t* symOut, uint32_t base, uint32_t count, uint32_t lane )
+{
+    wave_sync();
+    if ( 8 * lane < count ) {
+        const uint4 v = *reinterpret_cast<const uint4*>( &sh.ring[( base + 8 * lane ) & ( HUFF_RING - 1 )] );
+        *reinterpret_cast<uint4*>( symOut + base + 8 * lane ) = v;
+    }
+}
 
 __global__ __launch_bounds__( 64 * HUFF_WAVES ) void
 k_huff( const uint32_t* __restrict__ in_words,
@@ -281,6 +299,10 @@ k_huff( const uint32_t* __restrict__ in_words,
                 if ( valid && rank == 0 ) sh.running[len] = basePos + (uint32_t)__popcll( same );
                 wave_sync();
             }
+            if ( lane < 24 ) {
+                sh.limit[t][lane] = ( lane > (uint32_t)LUT_BITS && lane <= 20 )
+                                    ? ( ( sh.first[t][lane] + sh.count[t][lane] ) << ( 20 - lane ) ) : 0u;
+            }
             /* single-symbol half */
             const uint32_t lutMax = maxLen < (uint32_t)LUT_BITS ? maxLen : (uint32_t)LUT_BITS;
             for ( uint32_t e = lane; e < ( 1u << LUT_BITS ); e += 64 ) {
@@ -319,11 +341,17 @@ k_huff( const uint32_t* __restrict__ in_words,
 
     /* ---- symbol loop of Block::readBlockData, bzip2.hpp:709-723, window-parallel ---- */
     {
-        uint64_t pos = br.pos;
-        const uint64_t sizeBits = br.size_bits;
-        const uint64_t safeEnd = sizeBits > 256 ? sizeBits - 256 : 0;   /* below this no code can cross the end */
+        /* Bit positions inside the loop are 32-bit and relative to the word that holds the first symbol bit: a block
+         * ends long before 2^32 bits (900 096 symbols of at most 20 bits), and an input that is longer than that from
+         * here is clamped, which only moves the "end of input" checks out of reach. */
+        const uint64_t posBase = br.pos & ~31ull;
+        const uint32_t* const words = in_words + ( posBase >> 5 );
+        uint32_t pos = (uint32_t)( br.pos - posBase );
+        const uint32_t sizeBits = br.size_bits - posBase < 0xFFFF0000ull ? (uint32_t)( br.size_bits - posBase ) : 0xFFFF0000u;
+        const uint32_t safeEnd = sizeBits > 256 ? sizeBits - 256 : 0;   /* below this no code can cross the end */
+        const uint32_t fastEnd = safeEnd > 1100 ? safeEnd - 1100 : 0;   /* groups opened below this are "fast" */
         const uint32_t eob = symbolCount + 1;
-        uint32_t groupLeft = 0, fastLeft = 0, selIdx = 0, tcur = 0, tMaxLen = 0;
+        uint32_t groupLeft = 0, fastLeft = 0, selIdx = 0, tcur = 0;
         uint32_t limitV = 0;   /* lane l in (LUT_BITS, 20]: left-aligned (20 bit) end of the length-l code range */
         bool finished = false;
 
@@ -334,10 +362,17 @@ k_huff( const uint32_t* __restrict__ in_words,
 
         /* Each lane keeps the four stream words that start at the word of ITS bit position, loaded one window ahead:
          * a window advances by at most 64 bits, so the words needed next are among them. */
-        uint64_t myWord = ( pos + lane ) >> 5;
-        uint4 D = *reinterpret_cast<const uint4*>( in_words + myWord );
+        uint32_t myWord = ( pos + lane ) >> 5;
+        uint4 D = *reinterpret_cast<const uint4*>( words + myWord );
 
+#ifdef MI355X_BZ2_HUFF_PROFILE
+        uint64_t profSetup = 0, profChain = 0, profCommit = 0, profWindows = 0, profRefresh = 0, profGeneral = 0;
+#define HUFF_PROF_NOW() __builtin_readcyclecounter()
+#endif
         for ( ;; ) {
+#ifdef MI355X_BZ2_HUFF_PROFILE
+            const uint64_t profT00 = HUFF_PROF_NOW();
+#endif
             if ( groupLeft == 0 ) {
                 if ( selIdx >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
                 if ( ( selIdx & 7u ) == 0 ) {
@@ -350,19 +385,21 @@ k_huff( const uint32_t* __restrict__ in_words,
                 groupLeft = 50;
                 /* windows of this group start below pos + 50 * 20 bits: far enough from the end of the input and of
                  * the symbol buffer, the whole group may take the fast path */
-                fastLeft = ( pos + 1100 <= safeEnd && cnt + 50 <= SYM_CAP ) ? 50u : 0u;
-                tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
-                limitV = ( lane > (uint32_t)LUT_BITS && lane <= 20 )
-                         ? ( ( sh.first[tcur][lane] + sh.count[tcur][lane] ) << ( 20 - lane ) ) : 0u;
+                fastLeft = ( pos <= fastEnd && cnt + 50 <= SYM_CAP ) ? 50u : 0u;
+                limitV = sh.limit[tcur][lane < 24 ? lane : 23];   /* first use is far away: nobody waits for it here */
             }
+#ifdef MI355X_BZ2_HUFF_PROFILE
+            const uint64_t profT0 = HUFF_PROF_NOW();
+            profRefresh += profT0 - profT00;
+#endif
             /* my 32 stream bits, from the words fetched during the previous window; then fetch for the next one */
-            const uint64_t newWord = ( pos + lane ) >> 5;
-            const uint32_t dsel = (uint32_t)( newWord - myWord );   /* 0..2 */
+            const uint32_t newWord = ( pos + lane ) >> 5;
+            const uint32_t dsel = newWord - myWord;   /* 0..2 */
             const uint32_t hi = dsel == 0 ? D.x : ( dsel == 1 ? D.y : D.z );
             const uint32_t lo = dsel == 0 ? D.y : ( dsel == 1 ? D.z : D.w );
             myWord = newWord;
-            D = *reinterpret_cast<const uint4*>( in_words + myWord );
-            const uint32_t shv = (uint32_t)( pos + lane ) & 31u;
+            D = *reinterpret_cast<const uint4*>( words + myWord );
+            const uint32_t shv = ( pos + lane ) & 31u;
             const uint32_t bits32 = (uint32_t)( ( ( ( (uint64_t)hi << 32 ) | lo ) << shv ) >> 32 );
             const uint32_t E = sh.lut[tcur][bits32 >> ( 32 - LUT_BITS )];
             /* chain entries: lanes >= CHAIN_END never start a step (their entry reads as "stop"), which makes a step
@@ -377,6 +414,10 @@ k_huff( const uint32_t* __restrict__ in_words,
              * don't-care (masked by the 64-bit and). */
             uint32_t cur = 0;
             uint64_t mask = 0;
+#ifdef MI355X_BZ2_HUFF_PROFILE
+            asm volatile( "" :: "v"( Mv ) );
+            const uint64_t profT1 = HUFF_PROF_NOW();
+#endif
             {
                 uint32_t adv;
                 asm volatile(
@@ -398,27 +439,51 @@ k_huff( const uint32_t* __restrict__ in_words,
                     : [M] "v"( Mv )
                     : "scc", "s96", "s97", "s98", "s99" );
             }
+#ifdef MI355X_BZ2_HUFF_PROFILE
+            const uint64_t profT2 = HUFF_PROF_NOW();
+#endif
             uint32_t mySym = ( E & 0xFFFFu ) >> 5;
 
-            /* Fast path (almost every window): the chain ran to the end of the window and stays inside the current
-             * group.  End-of-block cannot be among the symbols (its entries read as "stop"), the end of the input and
-             * the symbol capacity were checked for the whole group when it was opened. */
+            /* Fast path (almost every window): the chain ran to the end of the window, or the 50-symbol group ends
+             * inside it -- then the window is cut in front of the first symbol of the next group, which was decoded
+             * with the wrong table.  End-of-block cannot be among the symbols (its entries read as "stop"); the end of
+             * the input and the symbol capacity were checked for the whole group when it was opened (fastLeft != 0). */
             {
-                const uint32_t nFast = (uint32_t)__popcll( mask );
-                if ( __builtin_expect( ( cur >= CHAIN_END ) & ( nFast <= fastLeft ), 1 ) ) {
-                    if ( __builtin_amdgcn_inverse_ballot_w64( mask ) ) {
-                        const uint32_t slot = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ),
-                                                                         __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, cnt ) );
-                        symOut[slot] = (uint16_t)mySym;
+                const uint32_t nAll = (uint32_t)__popcll( mask );
+                const bool cut = nAll > fastLeft;
+                if ( __builtin_expect( ( fastLeft != 0 ) & ( cut | ( cur >= CHAIN_END ) ), 1 ) ) {
+                    const bool isStart = __builtin_amdgcn_inverse_ballot_w64( mask );
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ),
+                                                                     __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
+                    uint32_t take = nAll, advance = cur;
+                    if ( cut ) {
+                        take = fastLeft;
+                        advance = (uint32_t)__builtin_ctzll( __ballot( isStart && rank == take ) );
                     }
-                    cnt += nFast;
-                    nsym += nFast;
-                    groupLeft -= nFast;
-                    fastLeft -= nFast;
-                    pos += cur;
+                    if ( isStart && rank < take ) sh.ring[( cnt + rank ) & ( HUFF_RING - 1 )] = (uint16_t)mySym;
+                    if ( ( ( cnt + take ) ^ cnt ) & ~( HUFF_RING / 2 - 1 ) ) {
+                        huff_flush( sh, symOut, cnt & ~( HUFF_RING / 2 - 1 ), HUFF_RING / 2, lane );
+                    }
+                    cnt += take;
+                    nsym += take;
+                    groupLeft -= take;
+                    fastLeft -= take;
+                    pos += advance;
+#ifdef MI355X_BZ2_HUFF_PROFILE
+                    {
+                        const uint64_t profT3 = HUFF_PROF_NOW();
+                        profSetup += profT1 - profT0;
+                        profChain += profT2 - profT1;
+                        profCommit += profT3 - profT2;
+                        ++profWindows;
+                    }
+#endif
                     continue;
                 }
             }
+#ifdef MI355X_BZ2_HUFF_PROFILE
+            ++profGeneral;
+#endif
 
             /* General path.  A stop at cur < CHAIN_END is resolved here: an end-of-block symbol (its short code is in
              * the single half of the entry) ends the chain; a code longer than LUT_BITS is found by comparing its 20-bit
@@ -514,7 +579,10 @@ k_huff( const uint32_t* __restrict__ in_words,
             if ( __builtin_amdgcn_inverse_ballot_w64( mask ) ) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ),
                                                                  __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
-                symOut[cnt + rank] = (uint16_t)mySym;
+                sh.ring[( cnt + rank ) & ( HUFF_RING - 1 )] = (uint16_t)mySym;
+            }
+            if ( ( ( cnt + nSyms ) ^ cnt ) & ~( HUFF_RING / 2 - 1 ) ) {
+                huff_flush( sh, symOut, cnt & ~( HUFF_RING / 2 - 1 ), HUFF_RING / 2, lane );
             }
             cnt += nSyms;
             nsym += nSyms;
@@ -526,11 +594,21 @@ k_huff( const uint32_t* __restrict__ in_words,
             if ( invalid ) {
                 /* no code of any length matches at `pos`: the reference runs out of bits first if fewer than the
                  * longest code remain (oracle: huff_decode) */
+                const uint32_t tMaxLen = sfl( sh.minmax[tcur] ) >> 8;
                 status = ( pos + tMaxLen > sizeBits ) ? ST_EOF : ST_INVALID_CODE;
                 break;
             }
         }
-        encSize = pos - start;
+#ifdef MI355X_BZ2_HUFF_PROFILE
+        if ( lane == 0 && ( b & 15u ) == 0 ) {
+            printf( "[k_huff profile] block %u: %llu fast + %llu general windows, cycles/window: refresh %.1f setup %.1f chain %.1f commit %.1f; bits %llu\n",
+                    b, (unsigned long long)profWindows, (unsigned long long)profGeneral, (double)profRefresh / profWindows, (double)profSetup / profWindows,
+                    (double)profChain / profWindows, (double)profCommit / profWindows, (unsigned long long)( posBase + pos - start ) );
+        }
+#endif
+        encSize = posBase + pos - start;
+        /* what is left in the ring (whole groups of eight: the symbol buffer is padded) */
+        huff_flush( sh, symOut, cnt & ~( HUFF_RING / 2 - 1 ), cnt & ( HUFF_RING / 2 - 1 ), lane );
     }
 
 finish:
@@ -565,37 +643,58 @@ finish:
 
 /* ============================================================================================================= */
 
-/** Move entry `ii` of this lane's list to the front; returns the entry.  `mine` = this lane's 256-byte list in LDS
- * (16-byte aligned): entries below `ii` shift up by one byte, four dwords (one ds_read_b128 / ds_write_b128) per trip. */
-__device__ __forceinline__ uint32_t
-mtf_lane_move( uint4* mine, uint32_t ii )
+/** Row p (0..15) of the byte-permute selectors for "insert a byte in front of a 16-byte group and drop byte p":
+ * dword j of the group becomes v_perm_b32( d_j, prev_j, sel_j ), prev_j = d_(j-1), prev_0 = the inserted byte in its
+ * byte 0.  Selector bytes 0-3 pick from prev_j, 4-7 from d_j: dwords below p's shift up completely, p's dword up to
+ * byte p & 3, the rest stays. */
+__device__ __forceinline__ uint4
+mtf_perm_row( uint32_t p )
 {
-    const uint32_t q = ii >> 2, r = ii & 3;   /* dword and byte of the entry */
-    const uint32_t q4 = q >> 2, r4 = q & 3;   /* uint4 that holds dword q, position inside it */
-    /* the entry itself (read first: the group that holds it is not touched by the loop below) goes to the front */
+    const uint32_t qd = p >> 2, r = p & 3u;
+    uint32_t sel[4];
+#pragma unroll
+    for ( uint32_t j = 0; j < 4; ++j ) {
+        uint32_t v;
+        if ( j < qd || ( j == qd && r == 3 ) ) v = 0x06050403u;      /* full shift */
+        else if ( j > qd ) v = 0x07060504u;                          /* keep */
+        else v = r == 0 ? 0x07060503u : ( r == 1 ? 0x07060403u : 0x07050403u );
+        if ( j == 0 && j <= qd ) v &= 0xFFFFFF00u;                   /* byte 0 of the group = byte 0 of prev_0 */
+        sel[j] = v;
+    }
+    return make_uint4( sel[0], sel[1], sel[2], sel[3] );
+}
+
+/** Move entry `ii` of this lane's list to the front; returns the entry.  `mine` = this lane's 256-byte list in LDS
+ * (16-byte aligned), `perm_rows` = the 16 rows of mtf_perm_row in LDS.  Entries below `ii` shift up by one byte: whole
+ * 16-byte groups with four v_alignbit per ds_read_b128 / ds_write_b128 trip, the group that holds the entry with four
+ * v_perm_b32.  Everything the last group needs (the group, the entry, the byte carried in from the group below, the
+ * selector row) is read up front, so the loads overlap and nothing depends on the trips. */
+__device__ __forceinline__ uint32_t
+mtf_lane_move( uint4* mine, const uint4* perm_rows, uint32_t ii )
+{
+    const uint32_t q4 = ii >> 4;
+    const uint8_t* const bytes = reinterpret_cast<const uint8_t*>( mine );
     const uint4 a = mine[q4];
-    const uint32_t dq = r4 == 0 ? a.x : ( r4 == 1 ? a.y : ( r4 == 2 ? a.z : a.w ) );
-    const uint32_t x = ( dq >> ( 8 * r ) ) & 0xFFu;
-    uint32_t carry = x;
+    const uint32_t x = bytes[ii];
+    const uint32_t below = bytes[q4 != 0 ? 16 * q4 - 1 : 0];
+    const uint4 sel = perm_rows[ii & 15u];
+    uint32_t carry = x << 24;   /* the byte that moves into the next group sits in the top byte */
     for ( uint32_t k = 0; k < q4; ++k ) {
         const uint4 g = mine[k];
         uint4 m;
-        m.x = ( g.x << 8 ) | carry;
-        m.y = ( g.y << 8 ) | ( g.x >> 24 );
-        m.z = ( g.z << 8 ) | ( g.y >> 24 );
-        m.w = ( g.w << 8 ) | ( g.z >> 24 );
-        carry = g.w >> 24;
+        m.x = __builtin_amdgcn_alignbit( g.x, carry, 24 );
+        m.y = __builtin_amdgcn_alignbit( g.y, g.x, 24 );
+        m.z = __builtin_amdgcn_alignbit( g.z, g.y, 24 );
+        m.w = __builtin_amdgcn_alignbit( g.w, g.z, 24 );
+        carry = g.w;
         mine[k] = m;
     }
-    /* last group: dwords 0..r4-1 shift completely, dword r4 up to byte r, the rest stays */
-    uint4 n = a;
-    uint32_t c = carry;
-    if ( r4 > 0 ) { n.x = ( a.x << 8 ) | c; c = a.x >> 24; }
-    if ( r4 > 1 ) { n.y = ( a.y << 8 ) | c; c = a.y >> 24; }
-    if ( r4 > 2 ) { n.z = ( a.z << 8 ) | c; c = a.z >> 24; }
-    const uint32_t lowMask = r == 3 ? 0xFFFFFFFFu : ( ( 1u << ( 8 * ( r + 1 ) ) ) - 1u );
-    const uint32_t part = ( ( ( dq << 8 ) | c ) & lowMask ) | ( dq & ~lowMask );
-    if ( r4 == 0 ) n.x = part; else if ( r4 == 1 ) n.y = part; else if ( r4 == 2 ) n.z = part; else n.w = part;
+    const uint32_t in = q4 != 0 ? below : x;
+    uint4 n;
+    n.x = __builtin_amdgcn_perm( a.x, in, sel.x );
+    n.y = __builtin_amdgcn_perm( a.y, a.x, sel.y );
+    n.z = __builtin_amdgcn_perm( a.z, a.y, sel.z );
+    n.w = __builtin_amdgcn_perm( a.w, a.z, sel.w );
     mine[q4] = n;
     return x;
 }
@@ -689,6 +788,7 @@ k_mtf( BlockMeta* __restrict__       meta,
        const uint32_t* __restrict__  order )
 {
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[MTF_THREADS * MTF_LANE_STRIDE];   /* 68 KiB */
+    __shared__ uint4 permRows[16];
     __shared__ uint8_t cur[256];
     __shared__ uint32_t starts[MTF_THREADS + 1];
     __shared__ unsigned long long waveTotals[MTF_THREADS / 64];
@@ -712,6 +812,7 @@ k_mtf( BlockMeta* __restrict__       meta,
     starts[t] = begin;
     if ( t == 0 ) { starts[MTF_THREADS] = n; firstError = 0xFFFFFFFFu; }
     cur[t] = stb_buf[(size_t)b * 256 + t];
+    if ( t < 16 ) permRows[t] = mtf_perm_row( t );
     for ( uint32_t k = 0; k < 16; ++k ) {
         const uint32_t e = 16 * k;
         mine[k] = make_uint4( ( e ) | ( ( e + 1 ) << 8 ) | ( ( e + 2 ) << 16 ) | ( ( e + 3 ) << 24 ),
@@ -736,7 +837,7 @@ k_mtf( BlockMeta* __restrict__       meta,
                 runPos <<= 1;
             } else {
                 if ( runPos != 0 ) { count += hh; runPos = 0; }
-                mtf_lane_move( mine, s - 1 );
+                mtf_lane_move( mine, permRows, s - 1 );
                 ++count;
             }
         }
@@ -788,7 +889,7 @@ k_mtf( BlockMeta* __restrict__       meta,
                 sink.fill( reinterpret_cast<const uint8_t*>( mine )[0], hh );
             }
             if ( sink.o >= MAX_N ) { err = ST_DATA_OVERFLOW; break; }
-            sink.put( mtf_lane_move( mine, s - 1 ) );
+            sink.put( mtf_lane_move( mine, permRows, s - 1 ) );
         }
         /* a run that is still open where the Huffman stage FAILED is never flushed by the reference */
         if ( err == 0 && runPos != 0 && ( end < n || hm.status == ST_OK ) ) {
