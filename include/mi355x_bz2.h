@@ -53,6 +53,7 @@ typedef enum mi355x_bz2_status {
     MI355X_BZ2_ERR_ORIGPTR_DATA = 14,     /* "origPtr error"                        bzip2.hpp:794-798 */
     MI355X_BZ2_ERR_CRC = 15,              /* "Calculated CRC ... mismatches"        bzip2.hpp:900-907 */
     MI355X_BZ2_ERR_STREAM_HEADER = 16,    /* readBzip2Header                        bzip2.hpp:114-142 */
+    MI355X_BZ2_ERR_STREAM_CRC = 17,       /* "Stream CRC ... does not match"        BZ2Reader.hpp:406-416 */
 
     /* errors of this implementation, no reference counterpart */
     MI355X_BZ2_ERR_OUTPUT_CAPACITY = 100,
@@ -200,6 +201,15 @@ int mi355x_bz2_reader_set_block_offsets( mi355x_bz2_reader* r, const uint64_t* b
                                          uint64_t n );
 /* joinThreads()                                                                :404-409 */
 int mi355x_bz2_reader_join_threads( mi355x_bz2_reader* r );
+
+/* Check of the combined CRC in every end-of-stream block against the block CRCs decoded in front of it
+ * (crc = rotl( crc, 1 ) ^ blockCRC, BZ2Reader.hpp:481-484; a mismatch fails the read with MI355X_BZ2_ERR_STREAM_CRC as
+ * BZ2Reader.hpp:406-416 throws).  The reference only does this in its serial reader, which is what parallelization
+ * == 1 selects there; ParallelBZ2Reader never checks.  Same default here: on for parallelization == 1, else off.
+ * The check covers streams whose blocks are decoded for the first time in order, i.e. not after set_block_offsets. */
+int mi355x_bz2_reader_set_verify_stream_crc( mi355x_bz2_reader* r, int enable );
+/* number of end-of-stream CRCs that have been compared (and matched) so far */
+uint64_t mi355x_bz2_reader_streams_verified( const mi355x_bz2_reader* r );
 
 /* BlockFetcher::Statistics subset (src/core/BlockFetcher.hpp:52-173) */
 typedef struct mi355x_bz2_reader_stats {

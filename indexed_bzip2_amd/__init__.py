@@ -6,4 +6,5 @@ include/mi355x_bz2.h.  All decoding happens in hand-written HIP kernels on gfx95
 __version__ = "0.1.0"
 
 from ._native import Bz2Error, Decoder, find_magic, lib, status_string  # noqa: F401
-from .reader import IndexedBzip2File, IndexedBzip2FileRaw, open  # noqa: F401
+from .reader import (IndexedBzip2File, IndexedBzip2FileRaw, open, read_block_offsets,  # noqa: F401
+                     write_block_offsets)

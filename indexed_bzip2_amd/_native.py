@@ -14,6 +14,7 @@ MAGIC_EOS = 0x177245385090
 
 OK = 0
 ERR_CRC = 15
+ERR_STREAM_CRC = 17
 ERR_NO_DEVICE = 102
 
 
@@ -106,6 +107,8 @@ SYMBOLS = [
     ("mi355x_bz2_reader_available_block_offsets", ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_uint64, _u64p]),
     ("mi355x_bz2_reader_set_block_offsets", ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_uint64]),
     ("mi355x_bz2_reader_join_threads", ctypes.c_int, [_vp]),
+    ("mi355x_bz2_reader_set_verify_stream_crc", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("mi355x_bz2_reader_streams_verified", ctypes.c_uint64, [_vp]),
     ("mi355x_bz2_reader_statistics", ctypes.c_int, [_vp, ctypes.POINTER(ReaderStats)]),
 ]
 

@@ -247,6 +247,7 @@ mi355x_bz2_status_string( int status )
     case MI355X_BZ2_ERR_DATA_OVERFLOW: return "[BZip2 block data] dbufCount > dbufSize";
     case MI355X_BZ2_ERR_ORIGPTR_DATA: return "[BZip2 block data] origPtr error";
     case MI355X_BZ2_ERR_CRC: return "Calculated CRC for block mismatches";
+    case MI355X_BZ2_ERR_STREAM_CRC: return "Stream CRC does not match calculated CRC";
     case MI355X_BZ2_ERR_STREAM_HEADER: return "Input header is not BZip2 magic string 'BZh' or invalid block size";
     case MI355X_BZ2_ERR_OUTPUT_CAPACITY: return "output capacity exceeded";
     case MI355X_BZ2_ERR_DEVICE: return "HIP runtime error";
@@ -544,6 +545,11 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
     const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
 
+    /* tuning knobs: most k_huff workgroups of a cheap group / of the expensive group (0 = one per block) */
+    const char* hc = std::getenv( "MI355X_BZ2_HUFF_GRID" );
+    const uint32_t huffCap = hc != nullptr && std::atoi( hc ) > 0 ? (uint32_t)std::atoi( hc ) : 0xFFFFFFFFu;
+    const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
+    const uint32_t huffCapExpensive = hce != nullptr && std::atoi( hce ) > 0 ? (uint32_t)std::atoi( hce ) : 0xFFFFFFFFu;
     for ( int launch = 0; launch < nGroups; ++launch ) {
         /* the expensive group is queued first, then the chunks from cheap to less cheap */
         const int g = expensiveGroup >= 0 ? ( launch == 0 ? expensiveGroup : launch - 1 ) : launch;
@@ -566,7 +572,8 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         uint32_t* const walkPre = c->dWalkPre + (size_t)g * ( c->capacity + 16 );
         const dim3 walkGrid( WALK_QUEUES * wgsPerXcd );
 
-        TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES ), dim3( 64 * HUFF_WAVES ), 0, q,
+        const uint32_t huffGrid = std::min( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES, g == expensiveGroup ? huffCapExpensive : huffCap );
+        TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
                       reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
                       m, order );
         TIMED_LAUNCH( c, g, q, 1, k_mtf, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );

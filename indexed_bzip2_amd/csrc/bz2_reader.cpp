@@ -25,6 +25,7 @@
 #include <iostream>
 #include <memory>
 #include <queue>
+#include <sstream>
 #include <string>
 
 #include "../../include/mi355x_bz2.h"
@@ -526,8 +527,12 @@ public:
     ParallelReader( std::shared_ptr<Source> source, size_t parallelization, int device ) :
         m_source( std::move( source ) ),
         m_parallelization( parallelization == 0 ? DEFAULT_PARALLELIZATION : parallelization ),
-        m_device( device )
+        m_device( device ),
+        m_verifyStreamCrc( parallelization == 1 )   /* the reference's serial reader checks, the parallel one does not */
     {}
+
+    void setVerifyStreamCrc( bool enable ) { m_verifyStreamCrc = enable; }
+    [[nodiscard]] uint64_t streamsVerified() const { return m_streamsVerified; }
 
     static constexpr size_t DEFAULT_PARALLELIZATION = 64;
 
@@ -592,6 +597,9 @@ public:
                 }
                 blockData = blockFetcher().get( *encodedOffsetInBits, dataBlockIndex );
                 m_blockMap.push( blockData->encodedOffsetInBits, blockData->encodedSizeInBits, blockData->dataSize );
+                /* BZ2Reader.hpp:481-484: new blocks arrive here in file order */
+                m_calculatedStreamCrc = ( ( m_calculatedStreamCrc << 1U ) | ( m_calculatedStreamCrc >> 31U ) )
+                                        ^ blockData->calculatedCRC;
 
                 /* EOS blocks have a different magic and are not found by the block finder (:204-238) */
                 if ( !blockData->isEndOfFile ) {
@@ -599,6 +607,19 @@ public:
                                                                       + blockData->encodedSizeInBits );
                     if ( next.isEndOfStreamBlock ) {
                         m_blockMap.push( next.encodedOffsetInBits, next.encodedSizeInBits, 0 );
+                        /* the end-of-stream block carries the CRC of the whole stream (BZ2Reader.hpp:406-416) */
+                        const auto calculated = m_calculatedStreamCrc;
+                        m_calculatedStreamCrc = 0;
+                        if ( m_verifyStreamCrc && m_streamCrcIntact ) {
+                            if ( next.expectedCRC != calculated ) {
+                                std::stringstream msg;
+                                msg << "[BZip2 block header] Stream CRC 0x" << std::hex << next.expectedCRC
+                                    << " does not match calculated CRC 0x" << calculated;
+                                fail( MI355X_BZ2_ERR_STREAM_CRC, msg.str() );
+                            }
+                            ++m_streamsVerified;
+                        }
+                        m_streamCrcIntact = true;
                         const auto nextStreamOffsetInBits = next.encodedOffsetInBits + next.encodedSizeInBits;
                         if ( nextStreamOffsetInBits < m_source->sizeInBits() ) {
                             if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(),
@@ -850,6 +871,11 @@ private:
     size_t m_currentPosition{ 0 };
     bool m_atEndOfFile{ false };
 
+    bool m_verifyStreamCrc;
+    bool m_streamCrcIntact{ true };         /* every block of the current stream went into m_calculatedStreamCrc */
+    uint32_t m_calculatedStreamCrc{ 0 };
+    uint64_t m_streamsVerified{ 0 };
+
     std::shared_ptr<BlockFinder> m_blockFinder;
     BlockMap m_blockMap;
     std::unique_ptr<GpuBlockFetcher> m_blockFetcher;
@@ -1071,6 +1097,18 @@ int
 mi355x_bz2_reader_join_threads( mi355x_bz2_reader* r )
 {
     return guarded( r, [] ( mi355x::ParallelReader& reader ) { reader.joinThreads(); } );
+}
+
+int
+mi355x_bz2_reader_set_verify_stream_crc( mi355x_bz2_reader* r, int enable )
+{
+    return guarded( r, [enable] ( mi355x::ParallelReader& reader ) { reader.setVerifyStreamCrc( enable != 0 ); } );
+}
+
+uint64_t
+mi355x_bz2_reader_streams_verified( const mi355x_bz2_reader* r )
+{
+    return ( r != nullptr && r->reader ) ? r->reader->streamsVerified() : 0;
 }
 
 int

@@ -89,27 +89,20 @@ huff_flush( const HuffShared& sh, uint16_t* symOut, uint32_t base, uint32_t coun
     }
 }
 
-__global__ __launch_bounds__( 64 * HUFF_WAVES ) void
-k_huff( const uint32_t* __restrict__ in_words,
-        uint64_t                     in_size_bytes,
-        const uint64_t* __restrict__ offsets,
-        BlockMeta* __restrict__      meta,
-        HuffMeta* __restrict__       hmeta,
-        uint8_t*                     sel_buf,
-        uint16_t* __restrict__       sym_buf,
-        uint8_t* __restrict__        stb_buf,
-        uint32_t                     n_blocks,
-        const uint32_t* __restrict__ order )
+/** Huffman stage of ONE block by one wavefront (see k_huff). */
+__device__ __forceinline__ void
+huff_block( HuffShared&                  sh,
+            const uint32_t* __restrict__ in_words,
+            uint64_t                     in_size_bytes,
+            const uint64_t* __restrict__ offsets,
+            BlockMeta* __restrict__      meta,
+            HuffMeta* __restrict__       hmeta,
+            uint8_t*                     sel_buf,
+            uint16_t* __restrict__       sym_buf,
+            uint8_t* __restrict__        stb_buf,
+            const uint32_t* __restrict__ order,
+            uint32_t                     slot )
 {
-    /* HUFF_WAVES independent blocks per workgroup, one per wavefront: a 256-thread workgroup is guaranteed to put its
-     * four waves on the four SIMDs of the CU, which single-wave workgroups are not (they were observed to pile up). */
-    __shared__ HuffShared shAll[HUFF_WAVES];
-    const uint32_t waveInGroup = sfl( threadIdx.x >> 6 );   /* wave-uniform: keeps all decoder state in SGPRs */
-    HuffShared& sh = shAll[waveInGroup];
-    /* longest-processing-time-first: slot i works on the block with the i-th largest compressed size, so the expensive
-     * (incompressible) blocks start first and the cheap ones fill the tail */
-    const uint32_t slot = blockIdx.x * HUFF_WAVES + waveInGroup;
-    if ( slot >= n_blocks ) return;
     const uint32_t b = sfl( order[slot] );
     const uint32_t lane = threadIdx.x & 63;
     uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
@@ -638,6 +631,32 @@ finish:
         hm.status = status;
         hm.active = active;
         hmeta[b] = hm;
+    }
+}
+
+__global__ __launch_bounds__( 64 * HUFF_WAVES ) void
+k_huff( const uint32_t* __restrict__ in_words,
+        uint64_t                     in_size_bytes,
+        const uint64_t* __restrict__ offsets,
+        BlockMeta* __restrict__      meta,
+        HuffMeta* __restrict__       hmeta,
+        uint8_t*                     sel_buf,
+        uint16_t* __restrict__       sym_buf,
+        uint8_t* __restrict__        stb_buf,
+        uint32_t                     n_blocks,
+        const uint32_t* __restrict__ order )
+{
+    /* HUFF_WAVES independent blocks per workgroup, one per wavefront: a 256-thread workgroup is guaranteed to put its
+     * four waves on the four SIMDs of the CU, which single-wave workgroups are not (they were observed to pile up). */
+    __shared__ HuffShared shAll[HUFF_WAVES];
+    const uint32_t waveInGroup = sfl( threadIdx.x >> 6 );   /* wave-uniform: keeps all decoder state in SGPRs */
+    /* longest-processing-time-first: slot i works on the block with the i-th largest compressed size, so the expensive
+     * (incompressible) blocks start first and the cheap ones fill the tail.  The grid may be smaller than the number
+     * of blocks (the host limits how many wavefronts share a CU's LDS with the other kernels of the pipeline): a
+     * wavefront then takes every gridDim-th slot. */
+    for ( uint32_t slot = blockIdx.x * HUFF_WAVES + waveInGroup; slot < n_blocks; slot += gridDim.x * HUFF_WAVES ) {
+        huff_block( shAll[waveInGroup], in_words, in_size_bytes, offsets, meta, hmeta, sel_buf, sym_buf, stb_buf, order, slot );
+        wave_sync();
     }
 }
 

@@ -7,6 +7,7 @@ blocks are decoded on the GPU.  `parallelization` = number of blocks kept in fli
 there is no serial CPU reader, so every value uses the GPU path.
 """
 import ctypes
+import builtins
 import io
 import os
 
@@ -158,6 +159,16 @@ class _IndexedBzip2FileParallel:
         self._require()
         self._check(N.lib().mi355x_bz2_reader_join_threads(self._h))
 
+    def set_verify_stream_crc(self, enable: bool):
+        """Check every end-of-stream CRC against the block CRCs in front of it (default: only with parallelization=1,
+        like the reference, whose serial reader checks and whose parallel reader does not)."""
+        self._require()
+        self._check(N.lib().mi355x_bz2_reader_set_verify_stream_crc(self._h, 1 if enable else 0))
+
+    def streams_verified(self) -> int:
+        self._require()
+        return int(N.lib().mi355x_bz2_reader_streams_verified(self._h))
+
     def statistics(self):
         self._require()
         st = N.ReaderStats()
@@ -204,8 +215,13 @@ class IndexedBzip2File(io.BufferedReader):
         self.size = self.bz2reader.size
         self.join_threads = self.bz2reader.join_threads
         self.statistics = self.bz2reader.statistics
+        self.set_verify_stream_crc = self.bz2reader.set_verify_stream_crc
+        self.streams_verified = self.bz2reader.streams_verified
 
         super().__init__(fobj, buffer_size=1024**2)
+
+
+builtins_open = builtins.open
 
 
 def open(filename, parallelization=0, device=-1):
@@ -214,3 +230,35 @@ def open(filename, parallelization=0, device=-1):
               with suitable read, seekable, seek, and tell methods.          (indexed_bzip2.pyx:340-345)
     """
     return IndexedBzip2File(filename, parallelization, device)
+
+
+def write_block_offsets(offsets, file):
+    """Block map as text, one "<compressed bit offset>,<decoded byte offset>" per line: the format `ibzip2 -L` writes
+    (src/tools/ibzip2.cpp:83-93) and `ibzip2-mi355x -L` reproduces.  `file` is a path or a text file object."""
+    text = "".join(f"{int(bits)},{int(byts)}\n" for bits, byts in sorted(offsets.items()))
+    if hasattr(file, "write"):
+        file.write(text)
+    else:
+        with builtins_open(file, "w") as f:
+            f.write(text)
+
+
+def read_block_offsets(file):
+    """Inverse of write_block_offsets: returns the dict that set_block_offsets() takes."""
+    if hasattr(file, "read"):
+        text = file.read()
+    else:
+        with builtins_open(file, "r") as f:
+            text = f.read()
+    if isinstance(text, bytes):
+        text = text.decode("ascii")
+    offsets = {}
+    for number, line in enumerate(text.splitlines(), 1):
+        line = line.strip()
+        if not line:
+            continue
+        parts = line.split(",")
+        if len(parts) != 2:
+            raise ValueError(f"line {number}: expected '<compressed bits>,<decoded bytes>', got {line!r}")
+        offsets[int(parts[0])] = int(parts[1])
+    return offsets

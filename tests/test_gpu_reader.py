@@ -183,3 +183,58 @@ def test_corrupt_block_surfaces_on_read(native, tmp_path):
         with pytest.raises(native.Bz2Error) as e:
             f.readall()
         assert e.value.status == 15
+
+
+def _corrupt_stream_crc(enc, oracle):
+    """Flip one bit of the combined CRC stored in the (first) end-of-stream block; block CRCs stay valid."""
+    eos = oracle.find_magic(enc, oracle.MAGIC_EOS)[0]
+    bad = bytearray(enc)
+    bit = eos + 48 + 5
+    bad[bit >> 3] ^= 0x80 >> (bit & 7)
+    return bytes(bad)
+
+
+def test_stream_crc_is_verified_like_the_serial_reference_reader(native, oracle):
+    """BZ2Reader.hpp:406-416 (serial reader, = parallelization 1 in the reference) throws on a wrong stream CRC;
+    ParallelBZ2Reader never looks at it.  Same matrix here, plus an explicit switch."""
+    parts = [datagen.text_like(300_000, 41), datagen.random_bytes(50_000, 42), b"tail"]
+    enc = datagen.multistream(parts, 1)
+    raw = b"".join(parts)
+    with native.open(io.BytesIO(enc), 1) as f:          # default on
+        assert f.read() == raw
+        assert f.streams_verified() == 3
+    with native.open(io.BytesIO(enc), 4) as f:          # default off
+        assert f.read() == raw
+        assert f.streams_verified() == 0
+    bad = _corrupt_stream_crc(enc, oracle)
+    with native.open(io.BytesIO(bad), 4) as f:          # parallel reader semantics: not noticed
+        assert f.read() == raw
+    with native.open(io.BytesIO(bad), 4) as f:
+        f.set_verify_stream_crc(True)
+        with pytest.raises(native.Bz2Error) as e:
+            f.read()
+        assert e.value.status == 17 and "Stream CRC" in str(e.value)
+    with native.IndexedBzip2FileRaw(io.BytesIO(bad), 1) as f:
+        with pytest.raises(native.Bz2Error) as e:
+            f.readall()
+        assert e.value.status == 17
+    with native.open(io.BytesIO(bad), 1) as f:
+        f.set_verify_stream_crc(False)
+        assert f.read() == raw
+
+
+def test_text_index_roundtrip(native, oracle, three_block_file, tmp_path):
+    """The `-L` text format (ibzip2.cpp:83-93) as an on-disk index: export, import into a fresh reader, seek."""
+    path, raw, enc = three_block_file
+    st, out, want_map, tg = oracle.decode_file(enc)
+    index = tmp_path / "index.csv"
+    with native.open(path, 4) as f:
+        native.write_block_offsets(f.block_offsets(), str(index))
+    assert index.read_text() == "".join(f"{k},{v}\n" for k, v in sorted(want_map.items()))
+    with native.open(path, 4) as g:
+        g.set_block_offsets(native.read_block_offsets(str(index)))
+        g.seek(1_700_000)
+        assert g.read(5000) == raw[1_700_000:1_705_000]
+        assert g.statistics()["blocks_decoded"] <= 3
+    with pytest.raises(ValueError):
+        native.read_block_offsets(io.StringIO("12;5\n"))

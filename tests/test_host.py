@@ -91,3 +91,18 @@ def test_stream_header(native, oracle):
     h = oracle.read_block_header(enc, eos[0])
     nxt = h["encoded_offset_bits"] + h["encoded_size_bits"]
     assert L.mi355x_bz2_read_stream_header(enc, len(enc), nxt) == 5
+
+
+def test_text_index_helpers(native, tmp_path):
+    """`-L` text format of the reference CLI (ibzip2.cpp:83-93): '<compressed bits>,<decoded bytes>' per line."""
+    offsets = {32: 0, 1845: 900000, 99999: 1800000, 100047: 1800000}
+    p = tmp_path / "map.csv"
+    native.write_block_offsets(offsets, str(p))
+    assert p.read_text() == "32,0\n1845,900000\n99999,1800000\n100047,1800000\n"
+    assert native.read_block_offsets(str(p)) == offsets
+    import io
+    buf = io.StringIO()
+    native.write_block_offsets(offsets, buf)
+    assert native.read_block_offsets(io.BytesIO(buf.getvalue().encode())) == offsets
+    with pytest.raises(ValueError):
+        native.read_block_offsets(io.StringIO("1,2,3\n"))
