@@ -136,6 +136,9 @@ const void* mi355x_bz2_output_device( const mi355x_bz2_ctx* ctx );
 /* Copy [offset, offset+size) of the last batch's output to host memory (D2H). */
 int mi355x_bz2_copy_output( mi355x_bz2_ctx* ctx, uint64_t offset, uint64_t size, void* host_dst );
 int mi355x_bz2_last_timings( const mi355x_bz2_ctx* ctx, mi355x_bz2_timings* timings );
+/* Only the duration of the last batch's kernel pipeline (HIP events before the first and after the last kernel): one
+ * event query instead of the ~90 that the per-kernel breakdown of mi355x_bz2_last_timings needs. */
+int mi355x_bz2_last_pipeline_ms( const mi355x_bz2_ctx* ctx, float* milliseconds );
 /* The hipStream_t the context launches on (as void*), so callers can order their own work after it. */
 void* mi355x_bz2_stream( const mi355x_bz2_ctx* ctx );
 

@@ -59,6 +59,9 @@ struct mi355x_bz2_ctx
     uint32_t* dSegLen{ nullptr };
     uint32_t* dSegSucc{ nullptr };
     uint32_t* dSegOff{ nullptr };
+    uint32_t* dSegCont{ nullptr };    /* [cap][SEG_STRIDE]: where a segment longer than STASH_BYTES goes on */
+    uint4*    dChain{ nullptr };      /* [cap][SEG_STRIDE]: segments in cycle order {segment, offset, length, continuation} */
+    uint32_t* dStash{ nullptr };      /* [cap][SEG_STRIDE][STASH_BYTES / 4]: first bytes of every segment */
     WalkPlan* dPlan{ nullptr };       /* [MAX_GROUPS]: one per group */
     uint32_t* dWalkBlk{ nullptr };    /* [MAX_GROUPS][cap + 16] */
     uint32_t* dWalkPre{ nullptr };
@@ -76,6 +79,8 @@ struct mi355x_bz2_ctx
     hipEvent_t ev[MAX_GROUPS][2 * MI355X_BZ2_MAX_KERNELS]{};   /* [group][2 * kernel + {start, end}] */
     hipEvent_t evStep[3]{};                                     /* step start, inputs uploaded, step end */
     hipEvent_t evGroupDone[MAX_GROUPS]{};
+    int timingGroups{ 0 };            /* groups of the last batch */
+    bool timingsResolved{ true };     /* timings.ms_kernel[] filled in for the last batch */
     uint32_t nKernels{ 0 };
     mi355x_bz2_timings timings{};
 };
@@ -145,6 +150,9 @@ freeScratch( mi355x_bz2_ctx* c )
     (void)hipFree( c->dSegLen ); c->dSegLen = nullptr;
     (void)hipFree( c->dSegSucc ); c->dSegSucc = nullptr;
     (void)hipFree( c->dSegOff ); c->dSegOff = nullptr;
+    (void)hipFree( c->dSegCont ); c->dSegCont = nullptr;
+    (void)hipFree( c->dChain ); c->dChain = nullptr;
+    (void)hipFree( c->dStash ); c->dStash = nullptr;
     (void)hipFree( c->dPlan ); c->dPlan = nullptr;
     (void)hipFree( c->dWalkBlk ); c->dWalkBlk = nullptr;
     (void)hipFree( c->dWalkPre ); c->dWalkPre = nullptr;
@@ -176,6 +184,9 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     HIP_TRY( c, hipMalloc( &c->dSegLen, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dSegSucc, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dSegOff, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dSegCont, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
+    HIP_TRY( c, hipMalloc( &c->dChain, (size_t)cap * SEG_STRIDE * sizeof( uint4 ) ) );
+    HIP_TRY( c, hipMalloc( &c->dStash, (size_t)cap * SEG_STRIDE * STASH_BYTES ) );
     HIP_TRY( c, hipMalloc( &c->dPlan, MAX_GROUPS * sizeof( WalkPlan ) ) );
     HIP_TRY( c, hipMalloc( &c->dWalkBlk, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dWalkPre, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
@@ -204,7 +215,7 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 namespace
 {
 const char* const KERNEL_NAMES[] = {
-    "k_huff", "k_mtf", "k_bwt_build", "k_walk2<false>", "k_link2", "k_walk2<true>", "k_replicate", "k_rle<false>",
+    "k_huff", "k_mtf", "k_bwt_build", "k_walk2<false>", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
     "k_rle<true>", "k_crc", "k_walk_plan"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
@@ -566,6 +577,9 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         uint32_t* const segLen = c->dSegLen + (size_t)first * SEG_STRIDE;
         uint32_t* const segSucc = c->dSegSucc + (size_t)first * SEG_STRIDE;
         uint32_t* const segOff = c->dSegOff + (size_t)first * SEG_STRIDE;
+        uint32_t* const segCont = c->dSegCont + (size_t)first * SEG_STRIDE;
+        uint4* const chain = c->dChain + (size_t)first * SEG_STRIDE;
+        uint32_t* const stash = c->dStash + (size_t)first * SEG_STRIDE * ( STASH_BYTES / 4 );
         const uint32_t* const order = c->dOrder + first;
         WalkPlan* const plan = c->dPlan + g;
         uint32_t* const walkBlk = c->dWalkBlk + (size_t)g * ( c->capacity + 16 );
@@ -580,10 +594,10 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
         TIMED_LAUNCH( c, g, q, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, segOff, rbuf, walkChunk );
-        TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segOff );
-        TIMED_LAUNCH( c, g, q, 5, k_walk2<true>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, segOff, rbuf, walkChunk );
+                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, segOff, rbuf, walkChunk, stash, segCont );
+        TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segCont, segOff, chain );
+        TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
+                      meta, tab, chain, stash, rbuf );
         TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf );
         TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );
         if ( g >= 1 ) {
@@ -656,15 +670,10 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
         }
     }
     if ( hipEventElapsedTime( &ms, c->evStep[0], c->evStep[2] ) == hipSuccess ) c->timings.ms_total = ms;   /* wall */
-    for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
-        for ( int g = 0; g < nGroups; ++g ) {
-            if ( ( k == 8 || k == 9 ) && g >= 1 ) continue;   /* 8, 9: once for the whole batch */
-            if ( hipEventElapsedTime( &ms, c->ev[g][2 * k], c->ev[g][2 * k + 1] ) == hipSuccess ) {
-                c->timings.ms_kernel[k] += ms;
-                c->timings.ms_kernel_sum += ms;
-            }
-        }
-    }
+    /* the per-kernel durations are read from the events on demand (mi355x_bz2_last_timings): ~90 event queries per
+     * batch cost milliseconds of host time that a caller who does not ask should not pay */
+    c->timingGroups = nGroups;
+    c->timingsResolved = false;
     return MI355X_BZ2_OK;
 }
 
@@ -691,7 +700,29 @@ int
 mi355x_bz2_last_timings( const mi355x_bz2_ctx* c, mi355x_bz2_timings* t )
 {
     if ( c == nullptr || t == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    if ( !c->timingsResolved && c->lastBlocks > 0 ) {
+        mi355x_bz2_ctx* const m = const_cast<mi355x_bz2_ctx*>( c );
+        float ms = 0;
+        for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
+            for ( int g = 0; g < c->timingGroups; ++g ) {
+                if ( ( k == 8 || k == 9 ) && g >= 1 ) continue;   /* 8, 9: once for the whole batch */
+                if ( hipEventElapsedTime( &ms, c->ev[g][2 * k], c->ev[g][2 * k + 1] ) == hipSuccess ) {
+                    m->timings.ms_kernel[k] += ms;
+                    m->timings.ms_kernel_sum += ms;
+                }
+            }
+        }
+        m->timingsResolved = true;
+    }
     *t = c->timings;
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_last_pipeline_ms( const mi355x_bz2_ctx* c, float* milliseconds )
+{
+    if ( c == nullptr || milliseconds == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    *milliseconds = c->timings.ms_total;
     return MI355X_BZ2_OK;
 }
 

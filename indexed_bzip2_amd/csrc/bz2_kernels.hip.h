@@ -59,6 +59,8 @@ struct BlockMeta
     uint32_t nseg;
     uint32_t walk_ok;    /* 1 if stages >= walk should run */
     uint32_t cycle_len;  /* length of the permutation cycle through origPtr (== N unless the block is periodic) */
+    uint32_t nchain;     /* number of walk segments on that cycle (k_link2) */
+    uint32_t pad;
 };
 
 struct CrcConsts

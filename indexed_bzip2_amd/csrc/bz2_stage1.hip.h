@@ -624,6 +624,8 @@ finish:
         mt.nseg = 0;
         mt.walk_ok = 0;
         mt.cycle_len = 0;
+        mt.nchain = 0;
+        mt.pad = 0;
         meta[b] = mt;
         HuffMeta hm;
         hm.n_stored = cnt;

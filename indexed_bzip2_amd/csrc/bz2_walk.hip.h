@@ -22,6 +22,9 @@ constexpr uint32_t WALK_THREADS = 256;
 constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
 constexpr uint32_t WALK_WGS_PER_XCD = 256;
 constexpr uint32_t WALK_QUEUES = 8;
+constexpr uint32_t STASH_BYTES = 64;         /* bytes of a segment the first walk keeps (one 64-B line per segment) */
+constexpr uint32_t EMIT_THREADS = 256;       /* segments (consecutive along the cycle) per k_emit workgroup */
+constexpr uint32_t EMIT_STAGE = 16384;       /* LDS bytes that collect their output before it is written in whole lines */
 
 struct WalkPlan
 {
@@ -82,12 +85,16 @@ __global__ __launch_bounds__( LINK_THREADS ) void
 k_link2( BlockMeta*                   meta,
          const uint32_t* __restrict__ seg_len,
          const uint32_t* __restrict__ seg_succ,
-         uint32_t* __restrict__       seg_off )
+         const uint32_t* __restrict__ seg_cont,
+         uint32_t* __restrict__       seg_off,
+         uint4* __restrict__          chain )
 {
     __shared__ uint16_t ssucc[SEG_STRIDE];          /* 64 KiB */
     __shared__ uint32_t subLen[LINK_MAX_SUB];       /* bytes covered by sub-chain s */
     __shared__ uint16_t subNext[LINK_MAX_SUB];      /* sub-chain that follows (index), 0xFFFF if broken */
     __shared__ uint32_t subOff[LINK_MAX_SUB];       /* output offset of the sub-chain, INVALID_OFF if off the cycle */
+    __shared__ uint32_t subCnt[LINK_MAX_SUB];       /* segments in sub-chain s */
+    __shared__ uint32_t subRank[LINK_MAX_SUB];      /* position of its first segment along the cycle */
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok ) return;
@@ -127,6 +134,7 @@ k_link2( BlockMeta*                   meta,
             if ( nextSub != 0xFFFFu ) break;
         }
         subLen[s] = sum;
+        subCnt[s] = steps;
         subNext[s] = (uint16_t)nextSub;
     }
     __syncthreads();
@@ -134,16 +142,19 @@ k_link2( BlockMeta*                   meta,
     /* link the sub-chains starting at the one that begins with `first` */
     if ( tid == 0 ) {
         const uint32_t start = firstExtra ? nSplit : first / LINK_SPLIT;
-        uint32_t s = start, off = 0, visited = 0;
+        uint32_t s = start, off = 0, visited = 0, rank = 0;
         bool ok = true;
         do {
             subOff[s] = off;
+            subRank[s] = rank;
             off += subLen[s];
+            rank += subCnt[s];
             s = subNext[s];
             ++visited;
             if ( s == 0xFFFFu || visited > nSub || off > N ) { ok = false; break; }
         } while ( s != start );
         meta[b].cycle_len = off;
+        meta[b].nchain = rank;
         if ( !ok || off == 0 ) {   /* unreachable for a permutation: guards against table corruption */
             meta[b].status = ST_CRC;
             meta[b].walk_ok = 0;
@@ -157,9 +168,15 @@ k_link2( BlockMeta*                   meta,
         if ( off == INVALID_OFF ) continue;
         uint32_t cur = s < nSplit ? s * LINK_SPLIT : first;
         uint32_t steps = 0;
+        uint32_t rank = subRank[s];
         for ( ;; ) {
+            const uint32_t len = seg_len[base + cur];
             seg_off[base + cur] = off;
-            off += seg_len[base + cur];
+            /* record for k_emit, in cycle order: segment, output offset, length, where its walk goes on after the
+             * STASH_BYTES the first pass kept */
+            chain[base + rank] = make_uint4( cur, off, len, len > STASH_BYTES ? seg_cont[base + cur] : 0u );
+            ++rank;
+            off += len;
             cur = ssucc[cur];
             ++steps;
             if ( cur == 0xFFFFu || steps > nseg || splitterOf( cur ) != 0xFFFFu ) break;
@@ -178,7 +195,9 @@ k_walk2( const BlockMeta* __restrict__ meta,
          uint32_t*                     seg_succ,
          const uint32_t*               seg_off,
          uint8_t*                      r_buf,
-         uint32_t                      chunk )
+         uint32_t                      chunk,
+         uint32_t*                     stash,      /* [block][segment][STASH_BYTES / 4], first pass only */
+         uint32_t*                     seg_cont )  /* table index of byte STASH_BYTES of a longer segment */
 {
     __shared__ uint32_t sBase, sNext, sK0;
     const uint32_t tid = threadIdx.x;
@@ -263,16 +282,127 @@ k_walk2( const BlockMeta* __restrict__ meta,
                         }
                     }
                 } else {
-                    do {
-                        ++len;
-                        p = ( e >> 8 ) & LF_MASK;
-                        e = tab[p];
-                    } while ( !( e & MARK ) && len < N );
+                    /* measure the segment and keep its first STASH_BYTES bytes (walk order) in the segment's own
+                     * 64-B line, 16 bytes per store: k_emit then needs no second gather pass for them */
+                    uint4* const line = reinterpret_cast<uint4*>( stash + sidx * ( STASH_BYTES / 4 ) );
+                    bool done = false;
+#pragma unroll
+                    for ( uint32_t quad = 0; quad < STASH_BYTES / 16; ++quad ) {
+                        if ( !done ) {
+                            uint32_t w[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                            for ( uint32_t i = 0; i < 16; ++i ) {
+                                if ( !done ) {
+                                    w[i >> 2] |= ( e & 0xFFu ) << ( 8 * ( i & 3u ) );
+                                    ++len;
+                                    p = ( e >> 8 ) & LF_MASK;
+                                    e = tab[p];
+                                    done = ( e & MARK ) || len >= N;
+                                }
+                            }
+                            line[quad] = make_uint4( w[0], w[1], w[2], w[3] );
+                        }
+                    }
+                    if ( !done ) {
+                        seg_cont[sidx] = p;   /* table index of byte STASH_BYTES */
+                        do {
+                            ++len;
+                            p = ( e >> 8 ) & LF_MASK;
+                            e = tab[p];
+                        } while ( !( e & MARK ) && len < N );
+                    }
                     seg_len[sidx] = len;
                     const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
                     seg_succ[sidx] = ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu;
                 }
                 my = atomicAdd( &sNext, 1u );
+            }
+        }
+    }
+}
+/**
+ * k_emit: the bytes of the walk, in output order.  A workgroup takes EMIT_THREADS segments that are CONSECUTIVE ALONG THE
+ * CYCLE (k_link2 wrote them down in that order), so together they cover one contiguous piece of the output.  Every lane
+ * fetches its segment's stashed line (the first 64 bytes, kept by the first walk), walks on only if the segment is
+ * longer, and drops the bytes at their place in an LDS image of that piece; the image then goes to memory in whole
+ * 16-byte units.  The second full gather pass and its partial-line writes (120 GB read + 25 GB written per 2 GiB, PMC)
+ * are gone.  Output addresses run backwards: byte i of the segment at offset `off` is R[N - 1 - off - i].
+ */
+__global__ __launch_bounds__( EMIT_THREADS ) void
+k_emit( const BlockMeta* __restrict__ meta,
+        const uint32_t* __restrict__  tab_buf,
+        const uint4* __restrict__     chain,
+        const uint32_t* __restrict__  stash,
+        uint8_t* __restrict__         r_buf )
+{
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t image[EMIT_STAGE + 16];
+    __shared__ uint32_t sLow;    /* lowest output address of the piece */
+    const uint32_t b = blockIdx.y;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t r0 = blockIdx.x * EMIT_THREADS;
+    if ( r0 >= mt.nchain ) return;
+    const uint32_t t = threadIdx.x;
+    const uint32_t N = mt.n;
+    const uint32_t count = mt.nchain - r0 < EMIT_THREADS ? mt.nchain - r0 : EMIT_THREADS;
+    const size_t base = (size_t)b * SEG_STRIDE;
+    uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
+    const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+
+    uint4 rec = make_uint4( 0, 0, 0, 0 );
+    if ( t < count ) rec = chain[base + r0 + t];
+    const uint32_t seg = rec.x, off = rec.y, len = rec.z;
+    /* the piece: [low, top], top = address of the first byte of the first segment */
+    __shared__ uint32_t sTop;
+    if ( t == count - 1 ) sLow = N - off - len;           /* N - 1 - (off + len - 1) */
+    if ( t == 0 ) sTop = N - 1 - off;
+    __syncthreads();
+    const uint32_t low = sLow, top = sTop;
+    const uint32_t imageBase = low & ~15u;                /* the image mirrors memory from a 16-byte boundary */
+
+    if ( t < count ) {
+        const uint32_t kept = len < STASH_BYTES ? len : STASH_BYTES;
+        const uint4* const line = reinterpret_cast<const uint4*>( stash + ( base + seg ) * ( STASH_BYTES / 4 ) );
+        uint32_t a = N - 1 - off;                         /* address of byte 0 */
+        const auto put = [&] ( uint32_t addr, uint32_t byte ) {
+            const uint32_t pos = addr - imageBase;
+            if ( pos < EMIT_STAGE ) image[pos] = (uint8_t)byte; else R[addr] = (uint8_t)byte;   /* oversized piece */
+        };
+#pragma unroll
+        for ( uint32_t quad = 0; quad < STASH_BYTES / 16; ++quad ) {
+            if ( quad * 16 < kept ) {
+                const uint4 v = line[quad];
+                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for ( uint32_t i = 0; i < 16; ++i ) {
+                    if ( quad * 16 + i < kept ) put( a - ( quad * 16 + i ), ( w[i >> 2] >> ( 8 * ( i & 3 ) ) ) & 0xFFu );
+                }
+            }
+        }
+        if ( len > STASH_BYTES ) {
+            uint32_t p = rec.w;
+            a -= STASH_BYTES;
+            for ( uint32_t i = STASH_BYTES; i < len; ++i ) {
+                const uint32_t e = tab[p];
+                put( a, e & 0xFFu );
+                --a;
+                p = ( e >> 8 ) & LF_MASK;
+            }
+        }
+    }
+    __syncthreads();
+
+    /* image -> memory: whole aligned 16-byte units where the piece covers them, bytes at its two ends (the units there
+     * are shared with the neighbouring pieces) */
+    const uint32_t endPos = ( top - imageBase + 1 ) < EMIT_STAGE ? ( top - imageBase + 1 ) : EMIT_STAGE;   /* exclusive */
+    const uint32_t beginPos = low - imageBase;
+    for ( uint32_t unit = t * 16; unit < endPos; unit += EMIT_THREADS * 16 ) {
+        if ( unit >= beginPos && unit + 16 <= endPos ) {
+            *reinterpret_cast<uint4*>( R + imageBase + unit ) = *reinterpret_cast<const uint4*>( image + unit );
+        } else {
+            for ( uint32_t i = 0; i < 16; ++i ) {
+                const uint32_t pos = unit + i;
+                if ( pos >= beginPos && pos < endPos ) R[imageBase + pos] = image[pos];
             }
         }
     }
