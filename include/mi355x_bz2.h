@@ -131,6 +131,15 @@ int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, 
 int mi355x_bz2_decode_batch( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offsets, uint32_t n_blocks,
                              mi355x_bz2_block_result* results, uint64_t* total_decoded );
 
+/* The same in two halves, for callers that keep the GPU busy across batches: _begin plans the batch and queues
+ * everything up to the decoded sizes (k_huff .. k_rle<false>) without waiting, _end waits for those, assigns the output
+ * offsets, runs the expansion and the CRC and fills `results` (n entries as given to _begin).  One batch per context
+ * can be in flight; two contexts used alternately (begin(A), begin(B), end(A), begin(A'), end(B), ...) overlap the
+ * Huffman stage of one batch with the throughput kernels of the other.  Each context drives 4 HIP streams: with two
+ * of them set GPU_MAX_HW_QUEUES=8 before the HIP runtime starts, or streams share hardware queues and serialize. */
+int mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offsets, uint32_t n_blocks );
+int mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* ctx, mi355x_bz2_block_result* results, uint64_t* total_decoded );
+
 /* Device pointer of the last batch's ragged output buffer (block i at data_offset). */
 const void* mi355x_bz2_output_device( const mi355x_bz2_ctx* ctx );
 /* Copy [offset, offset+size) of the last batch's output to host memory (D2H). */

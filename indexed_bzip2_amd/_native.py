@@ -79,6 +79,8 @@ SYMBOLS = [
     ("mi355x_bz2_set_input_host", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64]),
     ("mi355x_bz2_set_input_device", ctypes.c_int, [_vp, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_decode_batch", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.POINTER(BlockResult), _u64p]),
+    ("mi355x_bz2_decode_batch_begin", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32]),
+    ("mi355x_bz2_decode_batch_end", ctypes.c_int, [_vp, ctypes.POINTER(BlockResult), _u64p]),
     ("mi355x_bz2_output_device", _vp, [_vp]),
     ("mi355x_bz2_copy_output", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     ("mi355x_bz2_last_timings", ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
@@ -210,6 +212,17 @@ class Decoder:
         `results_array` (ctypes BlockResult[n], e.g. viewed through numpy.frombuffer).  Returns the decoded size."""
         total = ctypes.c_uint64()
         self._check(lib().mi355x_bz2_decode_batch(self._h, offsets_array, n, results_array, ctypes.byref(total)))
+        self.last_results = None
+        return total.value
+
+    def begin_batch(self, offsets_array, n: int):
+        """First half of decode_batch_into: queues the batch up to its decoded sizes and returns at once."""
+        self._check(lib().mi355x_bz2_decode_batch_begin(self._h, offsets_array, n))
+
+    def end_batch(self, results_array) -> int:
+        """Second half: output offsets, RLE expansion, CRC; returns the decoded size."""
+        total = ctypes.c_uint64()
+        self._check(lib().mi355x_bz2_decode_batch_end(self._h, results_array, ctypes.byref(total)))
         self.last_results = None
         return total.value
 

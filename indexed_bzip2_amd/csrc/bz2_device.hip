@@ -79,6 +79,10 @@ struct mi355x_bz2_ctx
     hipEvent_t ev[MAX_GROUPS][2 * MI355X_BZ2_MAX_KERNELS]{};   /* [group][2 * kernel + {start, end}] */
     hipEvent_t evStep[3]{};                                     /* step start, inputs uploaded, step end */
     hipEvent_t evGroupDone[MAX_GROUPS]{};
+    /* a batch between mi355x_bz2_decode_batch_begin and _end */
+    uint32_t pendingBlocks{ 0 };
+    int pendingGroups{ 0 }, pendingExpensive{ -1 };
+    uint32_t pendingGroupCount[MAX_GROUPS]{};
     int timingGroups{ 0 };            /* groups of the last batch */
     bool timingsResolved{ true };     /* timings.ms_kernel[] filled in for the last batch */
     uint32_t nKernels{ 0 };
@@ -449,8 +453,20 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
     if ( c == nullptr || ( n > 0 && ( offsets == nullptr || results == nullptr ) ) ) {
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
+    const int rc = mi355x_bz2_decode_batch_begin( c, offsets, n );
+    if ( rc != MI355X_BZ2_OK ) return rc;
+    return mi355x_bz2_decode_batch_end( c, results, totalDecoded );
+}
+
+int
+mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n )
+{
+    if ( c == nullptr || ( n > 0 && offsets == nullptr ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex );
-    if ( totalDecoded ) *totalDecoded = 0;
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "a batch is already in flight on this context: call mi355x_bz2_decode_batch_end first";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
     c->outSize = 0;
     c->lastBlocks = 0;
     if ( n == 0 ) return MI355X_BZ2_OK;
@@ -611,6 +627,27 @@ mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
 
     /* sizes -> host: output offsets are an exclusive scan of the decoded sizes IN INPUT ORDER (ragged, gap-free) */
     HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
+    c->pendingBlocks = n;
+    c->pendingGroups = nGroups;
+    c->pendingExpensive = expensiveGroup;
+    for ( int g = 0; g < MAX_GROUPS; ++g ) c->pendingGroupCount[g] = groupCount[g];
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* c, mi355x_bz2_block_result* results, uint64_t* totalDecoded )
+{
+    if ( c == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( totalDecoded ) *totalDecoded = 0;
+    const uint32_t n = c->pendingBlocks;
+    if ( n == 0 ) return MI355X_BZ2_OK;   /* empty batch */
+    if ( results == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    c->pendingBlocks = 0;
+    const int nGroups = c->pendingGroups, expensiveGroup = c->pendingExpensive;
+    const uint32_t* const groupCount = c->pendingGroupCount;
+    int rc = MI355X_BZ2_OK;
+    HIP_TRY( c, hipSetDevice( c->device ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     uint64_t total = 0;
     for ( uint32_t i = 0; i < n; ++i ) {
