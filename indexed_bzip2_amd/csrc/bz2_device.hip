@@ -219,8 +219,8 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 namespace
 {
 const char* const KERNEL_NAMES[] = {
-    "k_huff", "k_mtf", "k_bwt_build", "k_walk2<false>", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
-    "k_rle<true>", "k_crc", "k_walk_plan"
+    "k_huff", "k_mtf<272>", "k_bwt_build", "k_walk2<false>", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
+    "k_rle<true>", "k_crc", "k_walk_plan", "k_mtf<144>"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
 static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
@@ -606,7 +606,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
                       reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
                       m, order );
-        TIMED_LAUNCH( c, g, q, 1, k_mtf, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+        TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+        TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
         TIMED_LAUNCH( c, g, q, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, q,

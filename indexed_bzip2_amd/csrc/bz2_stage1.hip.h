@@ -25,6 +25,7 @@ namespace bz2gpu
 constexpr uint32_t SYM_STRIDE = 900224;       /* u16 symbols per block (n_sym <= N + 1 <= 900001 for valid blocks) */
 constexpr uint32_t SYM_CAP = 900096;
 constexpr uint32_t MTF_THREADS = 256;      /* lanes (= chunks) per block in k_mtf: one workgroup per block */
+constexpr uint32_t MTF_SMALL_STRIDE = 144;  /* lists of 128 entries for blocks with few symbols, see k_mtf */
 constexpr uint32_t MTF_LANE_STRIDE = 272;  /* bytes between the lists of consecutive lanes: 256 + 16, so that the 16-byte
                                               accesses of the 16 lanes served together fall on 64 distinct banks */
 constexpr uint32_t CHAIN_END = 54;      /* a chain step starts below this bit of the 64-bit window: the 10 start bits of
@@ -799,6 +800,12 @@ struct ByteSink
     }
 };
 
+/** LANE_STRIDE = bytes between the lists of consecutive lanes = list capacity + 16.  Two instances: 272 (any block) and
+ * MTF_SMALL_STRIDE (blocks that use at most MTF_SMALL_STRIDE - 16 symbols: text), whose 37 KB of LDS let four
+ * workgroups share a CU instead of two -- the kernel is bound by instruction issue at two waves per SIMD.  Both are
+ * launched over all blocks, a workgroup whose block belongs to the other instance returns at once.  Both strides keep
+ * the 16-byte accesses of 16 lanes on 64 distinct banks (stride / 4 mod 64 is an odd multiple of 4). */
+template<uint32_t LANE_STRIDE>
 __global__ __launch_bounds__( MTF_THREADS ) void
 k_mtf( BlockMeta* __restrict__       meta,
        const HuffMeta* __restrict__  hmeta,
@@ -808,7 +815,8 @@ k_mtf( BlockMeta* __restrict__       meta,
        uint32_t                      n_blocks,
        const uint32_t* __restrict__  order )
 {
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[MTF_THREADS * MTF_LANE_STRIDE];   /* 68 KiB */
+    constexpr uint32_t LIST_ENTRIES = LANE_STRIDE - 16;
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[MTF_THREADS * LANE_STRIDE];   /* 68 / 36 KiB */
     __shared__ uint4 permRows[16];
     __shared__ uint8_t cur[256];
     __shared__ uint32_t starts[MTF_THREADS + 1];
@@ -820,11 +828,12 @@ k_mtf( BlockMeta* __restrict__       meta,
     const uint32_t b = order[slot];
     const HuffMeta hm = hmeta[b];
     if ( !hm.active ) return;
+    if ( ( hm.symbol_count <= MTF_SMALL_STRIDE - 16 ) != ( LANE_STRIDE == MTF_SMALL_STRIDE ) ) return;   /* other instance */
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t n = hm.n_stored;
     const uint16_t* const sym = sym_buf + (size_t)b * SYM_STRIDE;
     uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
-    uint4* const mine = reinterpret_cast<uint4*>( listBytes + t * MTF_LANE_STRIDE );
+    uint4* const mine = reinterpret_cast<uint4*>( listBytes + t * LANE_STRIDE );
 
     /* chunk boundaries: never inside a RUNA/RUNB digit sequence */
     const uint32_t S = ( n + MTF_THREADS - 1 ) / MTF_THREADS;
@@ -834,7 +843,7 @@ k_mtf( BlockMeta* __restrict__       meta,
     if ( t == 0 ) { starts[MTF_THREADS] = n; firstError = 0xFFFFFFFFu; }
     cur[t] = stb_buf[(size_t)b * 256 + t];
     if ( t < 16 ) permRows[t] = mtf_perm_row( t );
-    for ( uint32_t k = 0; k < 16; ++k ) {
+    for ( uint32_t k = 0; k < LIST_ENTRIES / 16; ++k ) {
         const uint32_t e = 16 * k;
         mine[k] = make_uint4( ( e ) | ( ( e + 1 ) << 8 ) | ( ( e + 2 ) << 16 ) | ( ( e + 3 ) << 24 ),
                               ( e + 4 ) | ( ( e + 5 ) << 8 ) | ( ( e + 6 ) << 16 ) | ( ( e + 7 ) << 24 ),
@@ -880,12 +889,16 @@ k_mtf( BlockMeta* __restrict__       meta,
 
     /* ---- compose the chunk permutations in order: lane c's list becomes the list valid at the start of chunk c ---- */
     for ( uint32_t c = 0; c < MTF_THREADS; ++c ) {
-        uint8_t* const slotC = listBytes + c * MTF_LANE_STRIDE;
-        const uint8_t v = cur[slotC[t]];   /* entry t of the list after chunk c = old entry at the permuted position */
+        /* entries beyond the list capacity are never moved (symbols that do not occur): thread t has nothing to do */
+        uint8_t* const slotC = listBytes + c * LANE_STRIDE;
+        const bool mineToDo = t < LIST_ENTRIES;
+        const uint8_t v = mineToDo ? cur[slotC[t]] : 0;   /* entry t after chunk c = old entry at the permuted position */
         const uint8_t o = cur[t];
         __syncthreads();
-        slotC[t] = o;
-        cur[t] = v;
+        if ( mineToDo ) {
+            slotC[t] = o;
+            cur[t] = v;
+        }
         __syncthreads();
     }
 

@@ -133,3 +133,34 @@ def test_corrupt_crc_and_truncation(native, oracle, dec):
         results, total = dec.decode_batch([32])
         od, _ = oracle.decode_block(bad, 32)
         assert results[0]["status"] == od["status"], (cut, results[0], od)
+
+
+def test_begin_end_halves_and_two_contexts(native, oracle):
+    """mi355x_bz2_decode_batch_begin/_end: same results as the one-call form, one batch in flight per context, two
+    contexts interleaved (what bench.py does to overlap consecutive batches)."""
+    import numpy as np
+    parts = [datagen.text_like(1_200_000, 51), datagen.random_bytes(700_000, 52)]
+    encs = [datagen.compress(p, 9) for p in parts]
+    decs, arrays, wants = [], [], []
+    for enc, raw in zip(encs, parts):
+        d = native.Decoder()
+        d.set_input(enc)
+        offs = native.find_magic(enc)
+        decs.append(d)
+        arrays.append(d.make_arrays(offs) + (len(offs),))
+        wants.append((d.decode_batch(offs), raw))
+    for _ in range(2):
+        decs[0].begin_batch(arrays[0][0], arrays[0][2])
+        with pytest.raises(native.Bz2Error):
+            decs[0].begin_batch(arrays[0][0], arrays[0][2])        # a batch is already in flight on this context
+        decs[1].begin_batch(arrays[1][0], arrays[1][2])
+        for i in (0, 1):
+            total = decs[i].end_batch(arrays[i][1])
+            (want_results, want_total), raw = wants[i]
+            assert total == want_total == len(raw)
+            got = [arrays[i][1][k].as_dict() for k in range(arrays[i][2])]
+            assert got == want_results
+            assert decs[i].copy_output(0, total) == raw
+        assert decs[0].end_batch(arrays[0][1]) == 0                  # nothing in flight: empty batch
+    for d in decs:
+        d.close()
