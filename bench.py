@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("BZ2_BENCH_CACHE", "/tmp/indexed_bzip2_amd_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--contexts", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--contexts", type=int, default=2, choices=[1, 2, 3],
                     help="decoder contexts used alternately (double buffering): step k+1 is queued on the other context "
                          "before step k is finished, so its Huffman stage overlaps the throughput kernels of step k")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

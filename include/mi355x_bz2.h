@@ -14,6 +14,8 @@
  *        replaces  BitStringFinder<48>::find             src/core/BitStringFinder.hpp:158-285
  *                  ParallelBitStringFinder<48>::find     src/core/ParallelBitStringFinder.hpp:159-265
  *   3. Reader (scheduler + block map + user API):        mi355x_bz2_reader_*
+ *   4. Chunk decoding for rapidgzip:                     mi355x_bz2_decode_chunk
+ *        replaces  Bzip2Chunk::decodeChunk               src/rapidgzip/chunkdecoding/Bzip2Chunk.hpp:34-268
  *        replaces  indexed_bzip2::ParallelBZ2Reader      src/indexed_bzip2/ParallelBZ2Reader.hpp:39-498
  *                  (BZ2ReaderInterface                   src/indexed_bzip2/BZ2ReaderInterface.hpp:15-103)
  *        as bound by the Cython module                   python/indexed_bzip2/indexed_bzip2.pyx:26-67
@@ -54,6 +56,7 @@ typedef enum mi355x_bz2_status {
     MI355X_BZ2_ERR_CRC = 15,              /* "Calculated CRC ... mismatches"        bzip2.hpp:900-907 */
     MI355X_BZ2_ERR_STREAM_HEADER = 16,    /* readBzip2Header                        bzip2.hpp:114-142 */
     MI355X_BZ2_ERR_STREAM_CRC = 17,       /* "Stream CRC ... does not match"        BZ2Reader.hpp:406-416 */
+    MI355X_BZ2_ERR_NO_BLOCK_IN_RANGE = 18,/* rapidgzip::NoBlockInRange              Bzip2Chunk.hpp:262-266 */
 
     /* errors of this implementation, no reference counterpart */
     MI355X_BZ2_ERR_OUTPUT_CAPACITY = 100,
@@ -230,6 +233,42 @@ typedef struct mi355x_bz2_reader_stats {
     double   decode_seconds, wait_seconds;
 } mi355x_bz2_reader_stats;
 int mi355x_bz2_reader_statistics( const mi355x_bz2_reader* r, mi355x_bz2_reader_stats* stats );
+
+/* ------------------------------------------------------------------------------------------------ 4. chunk decoding */
+
+/* Counterpart of rapidgzip's bzip2 chunk decoder, Bzip2Chunk<ChunkData>::decodeChunk
+ * (src/rapidgzip/chunkdecoding/Bzip2Chunk.hpp:215-268) and decodeUnknownBzip2Chunk (:34-212): decodes the run of
+ * consecutive blocks that starts at chunk_offset_bits -- or, if nothing decodes there, at the first block magic behind it
+ * that does -- through end-of-stream blocks and the headers of following streams, up to (excluding) the first block that
+ * starts at or behind until_offset_bits, or until max_decoded_bytes have been produced (stopped_preemptively).
+ * `bytes` is the host view of the input that was given to mi355x_bz2_set_input_* (magic scan and headers are read on the
+ * host, all blocks of the range are decoded in ONE GPU batch).  The chunk's bytes are
+ * [data_offset, data_offset + decoded_size) of mi355x_bz2_output_device / mi355x_bz2_copy_output.
+ * blocks[k] (k < n_blocks): the records of the chunk's data blocks, data_offset relative to the chunk -- the
+ * {encoded offset, decoded offset} pairs are what ChunkData::appendDeflateBlockBoundary receives; footers[k]: the position
+ * behind every end-of-stream block and the decoded size so far (ChunkData::appendFooter).
+ * result->status: MI355X_BZ2_OK or MI355X_BZ2_ERR_NO_BLOCK_IN_RANGE (the reference throws NoBlockInRange). */
+typedef struct mi355x_bz2_chunk_boundary {
+    uint64_t encoded_offset_bits;
+    uint64_t decoded_offset;
+} mi355x_bz2_chunk_boundary;
+
+typedef struct mi355x_bz2_chunk_result {
+    uint64_t encoded_offset_bits;   /* where the chunk really starts */
+    uint64_t encoded_end_bits;      /* ChunkData::finalize( nextBlockOffset ) */
+    uint64_t decoded_size;
+    uint64_t data_offset;           /* of the chunk in the context's output buffer */
+    uint32_t n_blocks;
+    uint32_t n_footers;
+    int32_t  stopped_preemptively;
+    int32_t  status;
+} mi355x_bz2_chunk_result;
+
+int mi355x_bz2_decode_chunk( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size,
+                             uint64_t chunk_offset_bits, uint64_t until_offset_bits, uint64_t max_decoded_bytes,
+                             mi355x_bz2_chunk_result* result,
+                             mi355x_bz2_block_result* blocks, uint32_t blocks_capacity,
+                             mi355x_bz2_chunk_boundary* footers, uint32_t footers_capacity );
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,20 @@ class Timings(ctypes.Structure):
                 "kernels": {names[i]: self.ms_kernel[i] for i in range(self.n_kernels)}}
 
 
+class ChunkBoundary(ctypes.Structure):
+    _fields_ = [("encoded_offset_bits", ctypes.c_uint64), ("decoded_offset", ctypes.c_uint64)]
+
+
+class ChunkResult(ctypes.Structure):
+    _fields_ = [("encoded_offset_bits", ctypes.c_uint64), ("encoded_end_bits", ctypes.c_uint64),
+                ("decoded_size", ctypes.c_uint64), ("data_offset", ctypes.c_uint64),
+                ("n_blocks", ctypes.c_uint32), ("n_footers", ctypes.c_uint32),
+                ("stopped_preemptively", ctypes.c_int32), ("status", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class ReaderStats(ctypes.Structure):
     _fields_ = [("gets", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64), ("prefetch_hits", ctypes.c_uint64),
                 ("on_demand_fetches", ctypes.c_uint64), ("prefetches_submitted", ctypes.c_uint64),
@@ -113,6 +127,9 @@ SYMBOLS = [
     ("mi355x_bz2_reader_set_verify_stream_crc", ctypes.c_int, [_vp, ctypes.c_int]),
     ("mi355x_bz2_reader_streams_verified", ctypes.c_uint64, [_vp]),
     ("mi355x_bz2_reader_statistics", ctypes.c_int, [_vp, ctypes.POINTER(ReaderStats)]),
+    ("mi355x_bz2_decode_chunk", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_uint64, ctypes.POINTER(ChunkResult), ctypes.POINTER(BlockResult),
+                                               ctypes.c_uint32, ctypes.POINTER(ChunkBoundary), ctypes.c_uint32]),
 ]
 
 _lib = None
@@ -225,6 +242,21 @@ class Decoder:
         self._check(lib().mi355x_bz2_decode_batch_end(self._h, results_array, ctypes.byref(total)))
         self.last_results = None
         return total.value
+
+    def decode_chunk(self, data: bytes, chunk_offset: int, until_offset: int, max_decoded: int = 2**63):
+        """rapidgzip Bzip2Chunk::decodeChunk counterpart (mi355x_bz2_decode_chunk): `data` = the bytes given to
+        set_input().  Returns (chunk dict, block dicts, footers [(encoded bits, decoded offset)], chunk bytes)."""
+        cap = 4096
+        res = ChunkResult()
+        blocks = (BlockResult * cap)()
+        footers = (ChunkBoundary * cap)()
+        self._check(lib().mi355x_bz2_decode_chunk(self._h, data, len(data), chunk_offset, until_offset, max_decoded,
+                                                  ctypes.byref(res), blocks, cap, footers, cap))
+        d = res.as_dict()
+        payload = self.copy_output(d["data_offset"], d["decoded_size"]) if d["status"] == OK and d["decoded_size"] else b""
+        return (d, [blocks[i].as_dict() for i in range(min(cap, d["n_blocks"]))],
+                [(footers[i].encoded_offset_bits, footers[i].decoded_offset) for i in range(min(cap, d["n_footers"]))],
+                payload)
 
     def find_magic(self, magic: int = MAGIC_BLOCK):
         """Magic-bit scan of the resident input on the GPU (k_find_magic)."""

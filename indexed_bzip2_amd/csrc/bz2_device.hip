@@ -263,6 +263,7 @@ mi355x_bz2_status_string( int status )
     case MI355X_BZ2_ERR_ORIGPTR_DATA: return "[BZip2 block data] origPtr error";
     case MI355X_BZ2_ERR_CRC: return "Calculated CRC for block mismatches";
     case MI355X_BZ2_ERR_STREAM_CRC: return "Stream CRC does not match calculated CRC";
+    case MI355X_BZ2_ERR_NO_BLOCK_IN_RANGE: return "Failed to find any valid bzip2 block in the given range";
     case MI355X_BZ2_ERR_STREAM_HEADER: return "Input header is not BZip2 magic string 'BZh' or invalid block size";
     case MI355X_BZ2_ERR_OUTPUT_CAPACITY: return "output capacity exceeded";
     case MI355X_BZ2_ERR_DEVICE: return "HIP runtime error";
