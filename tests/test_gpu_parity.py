@@ -164,3 +164,47 @@ def test_begin_end_halves_and_two_contexts(native, oracle):
         assert decs[0].end_batch(arrays[0][1]) == 0                  # nothing in flight: empty batch
     for d in decs:
         d.close()
+
+
+@pytest.mark.parametrize("symbols", [1, 2, 15, 16, 17, 127, 128, 129, 255, 256])
+def test_alphabet_sizes_around_the_list_variants(native, oracle, dec, symbols):
+    """k_mtf runs in two instances (128-entry and 256-entry lists) chosen by the block's symbol count; 16-entry groups
+    inside a list.  Data with exactly `symbols` distinct byte values, skewed so that deep list positions occur."""
+    import numpy as np
+    rng = np.random.default_rng(1000 + symbols)
+    alphabet = rng.permutation(256)[:symbols].astype(np.uint8)
+    weights = 1.0 / np.arange(1, symbols + 1) ** 1.1
+    data = alphabet[rng.choice(symbols, size=260_000, p=weights / weights.sum())]
+    data[100_000:100_000 + symbols] = alphabet            # every value really occurs
+    raw = data.tobytes()
+    for level in (1, 9):
+        check_blocks(native, oracle, dec, datagen.compress(raw, level), raw)
+
+
+def test_randomized_inputs(native, oracle, dec):
+    """Seeded random structure: size, alphabet, run lengths, periodic stretches, level; every block record, the L column,
+    the pre-RLE1 stream and the payload against the oracle."""
+    import numpy as np
+    rng = np.random.default_rng(0xB21F)
+    for case in range(24):
+        n = int(rng.integers(1, 400_000))
+        kind = case % 4
+        if kind == 0:      # random bytes over a random alphabet
+            k = int(rng.integers(1, 257))
+            raw = rng.integers(0, k, n, dtype=np.uint8).tobytes()
+        elif kind == 1:    # runs of random lengths (exercises RLE1 counts and RUNA/RUNB)
+            lengths = rng.geometric(0.02, size=n // 20 + 1)
+            values = rng.integers(0, 256, lengths.size, dtype=np.uint8)
+            raw = np.repeat(values, lengths)[:n].tobytes()
+        elif kind == 2:    # periodic with a random period (LF permutation splits into cycles)
+            period = int(rng.integers(1, 50))
+            unit = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+            raw = (unit * (n // period + 1))[:n]
+        else:              # text-like with a few long runs
+            raw = bytearray(datagen.text_like(n, 700 + case))
+            for _ in range(5):
+                p = int(rng.integers(0, max(1, n - 3000)))
+                raw[p:p + int(rng.integers(1, 3000))] = bytes([int(rng.integers(0, 256))]) * len(raw[p:p + 1])
+            raw = bytes(raw[:n])
+        level = int(rng.integers(1, 10))
+        check_blocks(native, oracle, dec, datagen.compress(raw, level), raw, check_stages=case % 3 == 0)
