@@ -5,6 +5,12 @@ include/mi355x_bz2.h.  All decoding happens in hand-written HIP kernels on gfx95
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# the reader drives two decoder contexts with four HIP streams each: one hardware queue per stream (the HIP runtime
+# reads this when it starts, so it only helps if nothing has touched the GPU yet; an existing setting wins)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from ._native import Bz2Error, Decoder, find_magic, lib, status_string  # noqa: F401
 from .reader import (IndexedBzip2File, IndexedBzip2FileRaw, open, read_block_offsets,  # noqa: F401
                      write_block_offsets)

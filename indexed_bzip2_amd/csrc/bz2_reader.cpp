@@ -246,21 +246,33 @@ public:
         if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), 0 ) == 0 ) {
             fail( MI355X_BZ2_ERR_STREAM_HEADER );
         }
-        mi355x_bz2_config config{};
-        config.device = device;
-        config.max_batch_blocks = (uint32_t)std::min<size_t>( m_parallelization, 4096 );
-        const int rc = mi355x_bz2_create( &config, &m_ctx );
-        if ( rc != MI355X_BZ2_OK ) {
-            fail( rc );
+        /* Two decoder contexts, each with its own submission thread, once batches are large enough to be worth it:
+         * while one batch is copied to the host (and consumed), the next one is already being decoded. */
+        const size_t nContexts = m_parallelization >= 64 ? 2 : 1;
+        for ( size_t i = 0; i < nContexts; ++i ) {
+            mi355x_bz2_config config{};
+            config.device = device;
+            config.max_batch_blocks = (uint32_t)std::min<size_t>( m_parallelization, 4096 );
+            mi355x_bz2_ctx* ctx = nullptr;
+            int rc = mi355x_bz2_create( &config, &ctx );
+            std::string detail;
+            if ( rc == MI355X_BZ2_OK ) {
+                rc = mi355x_bz2_set_input_host( ctx, m_source->bytes(), m_source->size() );
+                if ( rc != MI355X_BZ2_OK ) {
+                    detail = mi355x_bz2_last_error( ctx );
+                    mi355x_bz2_destroy( ctx );
+                }
+            }
+            if ( rc != MI355X_BZ2_OK ) {
+                for ( auto* const c : m_ctxs ) mi355x_bz2_destroy( c );
+                m_ctxs.clear();
+                fail( rc, detail );
+            }
+            m_ctxs.push_back( ctx );
         }
-        const int rc2 = mi355x_bz2_set_input_host( m_ctx, m_source->bytes(), m_source->size() );
-        if ( rc2 != MI355X_BZ2_OK ) {
-            const std::string detail = mi355x_bz2_last_error( m_ctx );
-            mi355x_bz2_destroy( m_ctx );
-            m_ctx = nullptr;
-            fail( rc2, detail );
+        for ( auto* const ctx : m_ctxs ) {
+            m_workers.emplace_back( [this, ctx] () { workerMain( ctx ); } );
         }
-        m_worker = std::thread( [this] () { workerMain(); } );
     }
 
     ~GpuBlockFetcher()
@@ -270,13 +282,11 @@ public:
             m_stop = true;
             m_queueChanged.notify_all();
         }
-        if ( m_worker.joinable() ) {
-            m_worker.join();
+        for ( auto& worker : m_workers ) {
+            if ( worker.joinable() ) worker.join();
         }
         m_prefetching.clear();
-        if ( m_ctx != nullptr ) {
-            mi355x_bz2_destroy( m_ctx );
-        }
+        for ( auto* const ctx : m_ctxs ) mi355x_bz2_destroy( ctx );
     }
 
     /** BZ2BlockFetcher::readBlockHeader, BZ2BlockFetcher.hpp:64-82, for the EOS / next-stream probe on the caller
@@ -454,9 +464,11 @@ private:
     collectPrefetches( std::vector<uint64_t>& batch, bool onDemand, size_t requestedOffset )
     {
         processReadyPrefetches();
+        /* threadPoolSaturated, BlockFetcher.hpp:453-460: one batch of up to P blocks per decoder context */
         const auto inFlight = m_prefetching.size() + ( onDemand ? 1 : 0 );
-        if ( inFlight >= m_parallelization ) return;   /* threadPoolSaturated, BlockFetcher.hpp:453-460 */
-        const size_t room = m_parallelization - inFlight;
+        const size_t limit = m_parallelization * m_ctxs.size();
+        if ( inFlight >= limit ) return;
+        const size_t room = std::min( limit - inFlight, m_parallelization );
 
         const auto indexes = m_fetchingStrategy.prefetch( m_prefetchCache.capacity() );
         std::vector<uint64_t> candidates;
@@ -504,7 +516,7 @@ private:
 
     /** The single GPU submission thread: replaces ThreadPool workers calling decodeBlock (BlockFetcher.hpp:620-642). */
     void
-    workerMain()
+    workerMain( mi355x_bz2_ctx* const ctx )
     {
         while ( true ) {
             std::unique_ptr<Request> request;
@@ -521,18 +533,21 @@ private:
             const auto n = (uint32_t)request->offsets.size();
             std::vector<mi355x_bz2_block_result> results( n );
             uint64_t total = 0;
-            int rc = mi355x_bz2_decode_batch( m_ctx, request->offsets.data(), n, results.data(), &total );
+            int rc = mi355x_bz2_decode_batch( ctx, request->offsets.data(), n, results.data(), &total );
             std::shared_ptr<const uint8_t> buffer;
             if ( rc == MI355X_BZ2_OK ) {
                 buffer = m_hostBuffers->get( total, m_hostBuffers );
                 if ( !buffer ) {
                     rc = MI355X_BZ2_ERR_DEVICE;
                 } else if ( total > 0 ) {
-                    rc = mi355x_bz2_copy_output( m_ctx, 0, total, const_cast<uint8_t*>( buffer.get() ) );
+                    rc = mi355x_bz2_copy_output( ctx, 0, total, const_cast<uint8_t*>( buffer.get() ) );
                 }
             }
             if ( rc != MI355X_BZ2_OK ) {
-                m_workerError = mi355x_bz2_last_error( m_ctx );
+                {
+                    const std::scoped_lock lock( m_queueMutex );
+                    m_workerError = mi355x_bz2_last_error( ctx );
+                }
                 for ( auto& promise : request->promises ) {
                     promise.set_value( nullptr );
                 }
@@ -573,9 +588,9 @@ private:
     LruCache<size_t, bool> m_failedPrefetchCache;
     std::map<size_t, std::shared_future<BlockDataPtr> > m_prefetching;
 
-    mi355x_bz2_ctx* m_ctx{ nullptr };
+    std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };
-    std::thread m_worker;
+    std::vector<std::thread> m_workers;
     mutable std::mutex m_queueMutex;
     std::condition_variable m_queueChanged;
     std::queue<std::unique_ptr<Request> > m_queue;
