@@ -339,7 +339,8 @@ k_replicate( const BlockMeta* __restrict__ meta,
  * chunk is an exclusive scan.  Output sizes are a second (sum) scan.  One workgroup per block walks its tiles.
  * ============================================================================================================= */
 constexpr uint32_t RLE_THREADS = 512;
-constexpr uint32_t RLE_BYTES_PER_THREAD = 16;
+constexpr uint32_t RLE_BYTES_PER_THREAD = 32;   /* two 16-byte loads; the per-byte loops are unrolled with a predicate so
+                                                   that the bytes stay in registers (no dynamic indexing) */
 constexpr uint32_t RLE_TILE = RLE_THREADS * RLE_BYTES_PER_THREAD;
 constexpr uint32_t FN_IDENTITY = 0 | ( 1 << 3 ) | ( 2 << 6 ) | ( 3 << 9 ) | ( 4 << 12 );
 
@@ -388,20 +389,22 @@ k_rle( BlockMeta*                   meta,
 
     for ( uint32_t tile = 0; tile < N; tile += RLE_TILE ) {
         const uint32_t i0 = tile + tid * RLE_BYTES_PER_THREAD;
-        uint32_t wv[4] = { 0, 0, 0, 0 };
+        uint32_t wv[RLE_BYTES_PER_THREAD / 4] = {};
         uint32_t prev = 0;
         uint32_t nb = 0;
         if ( i0 < N ) {
             nb = N - i0 < RLE_BYTES_PER_THREAD ? N - i0 : RLE_BYTES_PER_THREAD;
             const uint4 v = *reinterpret_cast<const uint4*>( R + i0 );   /* R is padded to L_STRIDE */
+            const uint4 v2 = *reinterpret_cast<const uint4*>( R + i0 + 16 );
             wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+            wv[4] = v2.x; wv[5] = v2.y; wv[6] = v2.z; wv[7] = v2.w;
             prev = i0 > 0 ? R[i0 - 1] : 0x100u;
         }
         /* eq mask of my bytes */
         uint32_t eqMask = 0;
         {
             uint32_t p = prev;
-            for ( uint32_t q = 0; q < nb; ++q ) {
+            _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
                 eqMask |= ( c == p ? 1u : 0u ) << q;
                 p = c;
@@ -411,7 +414,7 @@ k_rle( BlockMeta*                   meta,
         uint32_t fn = FN_IDENTITY;
         if ( nb > 0 ) {
             uint32_t t0 = 0, t1 = 1, t2 = 2, t3 = 3, t4 = 4;
-            for ( uint32_t q = 0; q < nb; ++q ) {
+            _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const bool eq = ( eqMask >> q ) & 1u;
                 t0 = rle_step( t0, eq ); t1 = rle_step( t1, eq ); t2 = rle_step( t2, eq );
                 t3 = rle_step( t3, eq ); t4 = rle_step( t4, eq );
@@ -438,7 +441,7 @@ k_rle( BlockMeta*                   meta,
         uint32_t countMask = 0;
         {
             uint32_t kk = k;
-            for ( uint32_t q = 0; q < nb; ++q ) {
+            _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
                 if ( kk == 4 ) { mySize += c; countMask |= 1u << q; } else { mySize += 1; }
                 kk = rle_step( kk, ( eqMask >> q ) & 1u );
@@ -460,9 +463,27 @@ k_rle( BlockMeta*                   meta,
         const uint64_t myOff = sumIn + preS + ( inclS - mySize );
 
         if constexpr ( WRITE ) {
+            if ( countMask == 0 && nb == RLE_BYTES_PER_THREAD ) {
+                /* the common case: no repeat count among my bytes, they go out as they are.  Whole aligned dwords
+                 * (funnel-shifted by the misalignment of the destination), bytes only at the two ends. */
+                uint8_t* const d = dst + myOff;
+                const uint32_t head = ( 4u - ( (uint32_t)myOff & 3u ) ) & 3u;
+                for ( uint32_t z = 0; z < head; ++z ) d[z] = (uint8_t)( wv[0] >> ( 8 * z ) );
+                uint32_t* const d32 = reinterpret_cast<uint32_t*>( d + head );
+#pragma unroll
+                for ( uint32_t j = 0; j + 1 < RLE_BYTES_PER_THREAD / 4; ++j ) {
+                    d32[j] = __builtin_amdgcn_alignbyte( wv[j + 1], wv[j], head );
+                }
+                constexpr uint32_t LAST = RLE_BYTES_PER_THREAD / 4 - 1;
+                if ( head == 0 ) {
+                    d32[LAST] = wv[LAST];
+                } else {
+                    for ( uint32_t z = head; z < 4; ++z ) d[4 * LAST + z] = (uint8_t)( wv[LAST] >> ( 8 * z ) );
+                }
+            } else {
             uint64_t o = myOff;
             uint32_t p = prev;
-            for ( uint32_t q = 0; q < nb; ++q ) {
+            _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
                 if ( ( countMask >> q ) & 1u ) {
                     for ( uint32_t z = 0; z < c; ++z ) dst[o + z] = (uint8_t)p;
@@ -471,6 +492,7 @@ k_rle( BlockMeta*                   meta,
                     dst[o++] = (uint8_t)c;
                 }
                 p = c;
+            }
             }
         }
 
