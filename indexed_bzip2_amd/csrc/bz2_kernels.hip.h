@@ -298,7 +298,10 @@ k_bwt_build( const BlockMeta* __restrict__ meta,
     }
     __syncthreads();
 
-    /* pass 2: stable ranks, 64 positions per wave step */
+    /* pass 2: stable ranks, 64 positions per wave step; i % stride is kept incrementally (a division per position
+     * would cost more than the ranking itself) */
+    uint32_t rem = ( begin + lane ) % stride;
+    const uint32_t remStep = 64u % stride;
     for ( uint32_t base = begin; base < end; base += 64 ) {
         const uint32_t i = base + lane;
         const bool valid = i < end;
@@ -309,10 +312,12 @@ k_bwt_build( const BlockMeta* __restrict__ meta,
         if ( valid ) basePos = hist[wave][key];
         if ( valid ) {
             const uint32_t lf = basePos + rank;
-            const bool mark = ( i % stride == 0 ) || ( i == origPtr );
+            const bool mark = ( rem == 0 ) || ( i == origPtr );
             tab[i] = ( lf << 8 ) | key | ( mark ? MARK : 0u );
             if ( rank == 0 ) hist[wave][key] = basePos + (uint32_t)__popcll( same );
         }
+        rem += remStep;
+        if ( rem >= stride ) rem -= stride;
     }
 }
 
