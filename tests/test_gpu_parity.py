@@ -208,3 +208,14 @@ def test_randomized_inputs(native, oracle, dec):
             raw = bytes(raw[:n])
         level = int(rng.integers(1, 10))
         check_blocks(native, oracle, dec, datagen.compress(raw, level), raw, check_stages=case % 3 == 0)
+
+
+def test_maximal_rle_expansion(native, oracle, dec):
+    """One value repeated 60 MB: RLE1 packs 255 + 4 bytes into 5, so a 900 kB block decodes to ~46 MB (the case the
+    reference's chunk decoder guards with its 64 MiB limit, Bzip2Chunk.hpp:171-184).  Output offsets and the RLE scan
+    work far beyond N here; 0xFB as the value also makes every count byte equal to the data byte."""
+    for value in (0, 0xFB):
+        raw = bytes([value]) * 60_000_000
+        enc = datagen.compress(raw, 9)
+        results = check_blocks(native, oracle, dec, enc, raw, check_stages=False)
+        assert max(r["decoded_size"] for r in results) > 40_000_000
