@@ -186,6 +186,8 @@ def main():
     gather_buf = None
     expected = meta["decoded_bytes"]
 
+    gather_done = {}
+
     def gather(total, decoder):
         """Decoded extents of all ranks -> rank 0 HBM (RCCL over xGMI)."""
         nonlocal gather_buf
@@ -198,6 +200,12 @@ def main():
         buf, _sizes = gather_extents(mine, rank, world, gather_buf)
         if rank == 0:
             gather_buf = buf
+        if args.backend == "nccl":
+            # the sends read the context's output buffer asynchronously: its next expansion must not start before
+            # they are done (checked in finish() before that context's next end_batch)
+            done = torch.cuda.Event()
+            done.record()
+            gather_done[id(decoder)] = done
 
     import numpy as np
     decs = [dec]
@@ -212,6 +220,9 @@ def main():
     def finish(k):
         """Second half of step k on its context: output offsets, expansion, CRC; every block's status checked; decoded
         extents gathered for N > 1."""
+        pending = gather_done.pop(id(decs[k % len(decs)]), None)
+        if pending is not None:
+            pending.synchronize()   # long finished in practice: two steps have passed
         total = decs[k % len(decs)].end_batch(res_cs[k % len(decs)])
         assert total == expected and not status_views[k % len(decs)].any(), "a block failed"
         gather(total, decs[k % len(decs)])
