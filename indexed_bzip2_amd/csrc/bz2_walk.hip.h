@@ -22,7 +22,8 @@ constexpr uint32_t WALK_THREADS = 256;
 constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
 constexpr uint32_t WALK_WGS_PER_XCD = 256;
 constexpr uint32_t WALK_QUEUES = 8;
-constexpr uint32_t STASH_BYTES = 64;         /* bytes of a segment the first walk keeps (one 64-B line per segment) */
+constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps (two 64-B lines per segment: 1 % of the
+                                                bytes lie beyond, 10 % with one line) */
 constexpr uint32_t EMIT_THREADS = 256;       /* segments (consecutive along the cycle) per k_emit workgroup */
 constexpr uint32_t EMIT_STAGE = 16384;       /* LDS bytes that collect their output before it is written in whole lines */
 
