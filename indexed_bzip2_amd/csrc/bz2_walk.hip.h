@@ -301,20 +301,27 @@ k_walk2( const BlockMeta* __restrict__ meta,
                                     done = ( e & MARK ) || len >= N;
                                 }
                             }
-                            line[quad] = make_uint4( w[0], w[1], w[2], w[3] );
+                            /* written once, read much later by k_emit: keep it out of the way of the table lines in L2 */
+                            {
+                                uint32_t* const q = reinterpret_cast<uint32_t*>( line + quad );
+                                __builtin_nontemporal_store( w[0], q );
+                                __builtin_nontemporal_store( w[1], q + 1 );
+                                __builtin_nontemporal_store( w[2], q + 2 );
+                                __builtin_nontemporal_store( w[3], q + 3 );
+                            }
                         }
                     }
                     if ( !done ) {
-                        seg_cont[sidx] = p;   /* table index of byte STASH_BYTES */
+                        __builtin_nontemporal_store( p, seg_cont + sidx );   /* table index of byte STASH_BYTES */
                         do {
                             ++len;
                             p = ( e >> 8 ) & LF_MASK;
                             e = tab[p];
                         } while ( !( e & MARK ) && len < N );
                     }
-                    seg_len[sidx] = len;
+                    __builtin_nontemporal_store( len, seg_len + sidx );
                     const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
-                    seg_succ[sidx] = ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu;
+                    __builtin_nontemporal_store( ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu, seg_succ + sidx );
                 }
                 my = atomicAdd( &sNext, 1u );
             }
