@@ -8,8 +8,10 @@
  *   -L : "<compressed bit offset>,<decoded byte offset>" per line             (dumpOffsets, ibzip2.cpp:83-93)
  * The reference parses its command line with cxxopts (an un-vendored submodule); this parser is our own.
  *
- * Differences: -P is the number of blocks kept in flight per GPU batch (0 = default), there is no serial CPU decoder
- * behind -P 1; standard input is read completely into memory first (the GPU decodes from a resident copy anyway).
+ * Differences: -P is the number of blocks kept in flight per GPU batch and defaults to 0 = automatic (512): there is no
+ * serial CPU decoder behind -P 1, which would mean one block per GPU launch here.  What the reference's serial decoder
+ * checks and its parallel one does not -- the combined CRC of every stream -- is checked with -t (and with -P 1).
+ * Standard input is read completely into memory first (the GPU decodes from a resident copy anyway).
  */
 #include <algorithm>
 #include <cerrno>
@@ -39,7 +41,7 @@ struct Options
     bool listCompressed{ false }, listOffsets{ false };
     std::string input, output, listCompressedPath, listOffsetsPath;
     bool hasOutput{ false };
-    unsigned finderParallelism{ 1 }, decoderParallelism{ 1 }, bufferSize{ 0 };
+    unsigned finderParallelism{ 1 }, decoderParallelism{ 0 }, bufferSize{ 0 };
     int device{ -1 };
 };
 
@@ -61,7 +63,8 @@ printHelp()
         "  -t, --test                    Test compressed file integrity.\n"
         "  -p, --block-finder-parallelism arg\n"
         "                                Threads of the host block finder (0 = automatic). (default: 1)\n"
-        "  -P, --decoder-parallelism arg Blocks kept in flight per GPU batch (0 = automatic). (default: 1)\n"
+        "  -P, --decoder-parallelism arg Blocks kept in flight per GPU batch (0 = automatic). (default: 0; the\n"
+        "                                reference defaults to 1 = its serial CPU decoder, which does not exist here)\n"
         "      --device arg              GPU to use (default: current device)\n\n"
         " Output options:\n"
         "  -h, --help                    Print this help message.\n"
@@ -436,6 +439,7 @@ main( int argc, char** argv )
             if ( outFd >= 0 && !writingToStdout ) ::close( outFd );
             return 1;
         }
+        if ( o.test ) (void)mi355x_bz2_reader_set_verify_stream_crc( reader, 1 );
         const auto fail = [&] ( int status ) {
             const char* detail = mi355x_bz2_reader_last_error( reader );
             std::cerr << "Decoding failed: " << mi355x_bz2_status_string( status );

@@ -140,3 +140,20 @@ def test_stdin_to_stdout_and_corrupt_input(cli):
     assert r.returncode == 1 and b"Decoding failed" in r.stderr
     r = run(cli, "-d", stdin=b"not a bzip2 file at all")
     assert r.returncode == 1
+
+
+@pytest.mark.gpu
+def test_test_mode_checks_the_stream_crc(cli, oracle):
+    """-t verifies the combined CRC in the end-of-stream block (what the reference's default serial decoder does,
+    BZ2Reader.hpp:406-416); plain -d with the parallel reader semantics does not."""
+    enc = datagen.compress(datagen.text_like(300_000, 71), 9)
+    eos = oracle.find_magic(enc, oracle.MAGIC_EOS)[0]
+    bad = bytearray(enc)
+    bit = eos + 48 + 9
+    bad[bit >> 3] ^= 0x80 >> (bit & 7)
+    r = run(cli, "-d", "-t", stdin=bytes(bad))
+    assert r.returncode == 1 and b"Stream CRC" in r.stderr
+    r = run(cli, "-d", stdin=bytes(bad))
+    assert r.returncode == 0 and len(r.stdout) == 300_000
+    r = run(cli, "-d", "-t", stdin=enc)
+    assert r.returncode == 0 and len(r.stdout) == 300_000
