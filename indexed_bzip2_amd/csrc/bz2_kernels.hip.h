@@ -28,7 +28,9 @@ constexpr uint32_t TAB_STRIDE = 1u << 20;     /* u32 entries per block: every 20
 constexpr uint32_t KMAX = 32768;              /* max regular walk segments per block (+1 for origPtr) */
 constexpr uint32_t SEG_STRIDE = KMAX + 64;
 constexpr uint32_t MIN_SEG_STRIDE = 16;
-constexpr int LUT_BITS = 9;
+constexpr int LUT_BITS = 8;    /* index bits of the k_huff look-up tables: 9 makes k_huff itself 8 % faster (57 vs 61.5 ms) but
+                                  its 20 KB of LDS per wave instead of 14 KB cost the co-running kernels more (93 vs 91 ms
+                                  per step); 10 -> 108 ms, 7 -> every window meets a long code */
 constexpr uint32_t MARK = 0x80000000u;
 constexpr uint32_t LF_MASK = 0xFFFFFu;
 constexpr uint32_t INVALID_OFF = 0xFFFFFFFFu;
