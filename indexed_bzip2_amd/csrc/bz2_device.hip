@@ -171,9 +171,10 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     if ( nBlocks <= c->capacity ) return MI355X_BZ2_OK;
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     freeScratch( c );
+    /* about 13 MB of scratch per block: powers of two while that is cheap, multiples of 256 blocks beyond */
     uint32_t cap = 64;
-    while ( cap < nBlocks ) cap *= 2;
-    if ( cap > nBlocks && (uint64_t)cap * TAB_STRIDE * 4 > ( 64ull << 30 ) ) cap = nBlocks;  /* keep large batches tight */
+    while ( cap < nBlocks && cap < 512 ) cap *= 2;
+    if ( cap < nBlocks ) cap = ( nBlocks + 255u ) & ~255u;
     HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dOrder, (size_t)cap * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipHostMalloc( &c->hOrder, (size_t)cap * sizeof( uint32_t ), hipHostMallocDefault ) );
