@@ -220,7 +220,7 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 namespace
 {
 const char* const KERNEL_NAMES[] = {
-    "k_huff", "k_mtf<272>", "k_bwt_build", "k_walk2<false>", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
+    "k_huff", "k_mtf<272>", "k_bwt_build", "k_walk", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
     "k_rle<true>", "k_crc", "k_walk_plan", "k_mtf<144>"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
@@ -612,8 +612,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
-        TIMED_LAUNCH( c, g, q, 3, k_walk2<false>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, segOff, rbuf, walkChunk, stash, segCont );
+        TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
+                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
         TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segCont, segOff, chain );
         TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
                       meta, tab, chain, stash, rbuf );

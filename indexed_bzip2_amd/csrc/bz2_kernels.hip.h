@@ -7,7 +7,7 @@
  *   k_huff, k_mtf (bz2_stage1.hip.h)  header, tables, Huffman, RUNA/RUNB, MTF -> L column (u8[N])   bzip2.hpp:479-807
  *   k_bwt_build   per block: byte histogram, stable ranks -> packed LF table u32[N] = LF<<8 | byte | MARK
  *                 (coalesced writes; replaces the scatter of prepare(), bzip2.hpp:810-847)
- *   k_walk2<false>, k_link2, k_walk2<true> (bz2_walk.hip.h)  multi-segment form of the N-step walk  bzip2.hpp:872-879
+ *   k_walk, k_link2, k_emit (bz2_walk.hip.h)  multi-segment form of the N-step walk  bzip2.hpp:872-879
  *   k_rle<false>  RLE1 as a 5-state scan: decoded size D per block                      bzip2.hpp:881-896
  *   k_rle<true>   expansion into the batch output buffer
  *   k_crc         bzip2 CRC-32 of the D bytes by chunk CRCs + GF(2) shift-combine        bzip2.hpp:59-91, 900-907

@@ -1,5 +1,5 @@
 /**
- * bz2_walk.hip.h -- inverse-BWT walk, XCD-affine work-queue form (replaces the one-lane-per-segment grid k_walk).
+ * bz2_walk.hip.h -- inverse-BWT walk, XCD-affine work-queue form (replaces the first version's one-lane-per-segment grid).
  *
  * Why: PMC showed each of the 2 x 2.3 G four-byte gathers of the grid version pulling a full 64-B line across the fabric
  * (FETCH_SIZE 127 GB per pass for 9 GB of tables): ~60 blocks' tables (230 MB) were in flight at once, so nothing
@@ -31,8 +31,8 @@ struct WalkPlan
 {
     uint32_t q_begin[WALK_QUEUES + 1];   /* entry range of queue q in blk[] / pre[] */
     uint32_t q_total[WALK_QUEUES];       /* segments in queue q */
-    uint32_t ctr[2][WALK_QUEUES];        /* [pass][queue]: next unclaimed segment (atomic) */
-    uint32_t pad[7];
+    uint32_t ctr[WALK_QUEUES];           /* next unclaimed segment of the queue (atomic) */
+    uint32_t pad[15];
 };
 
 /** One workgroup: lays out the queues (block i -> queue i mod 8) and zeroes the counters. */
@@ -60,8 +60,7 @@ k_walk_plan( const BlockMeta* __restrict__ meta, uint32_t n, WalkPlan* plan, uin
             ++idx;
         }
         plan->q_total[t] = acc;
-        plan->ctr[0][t] = 0;
-        plan->ctr[1][t] = 0;
+        plan->ctr[t] = 0;
     }
 }
 
@@ -185,19 +184,16 @@ k_link2( BlockMeta*                   meta,
     }
 }
 
-template<bool EMIT>
 __global__ __launch_bounds__( WALK_THREADS ) void
-k_walk2( const BlockMeta* __restrict__ meta,
+k_walk( const BlockMeta* __restrict__ meta,
          const uint32_t* __restrict__  tab_buf,
          WalkPlan*                     plan,
          const uint32_t* __restrict__  blk,
          const uint32_t* __restrict__  pre,
          uint32_t*                     seg_len,
          uint32_t*                     seg_succ,
-         const uint32_t*               seg_off,
-         uint8_t*                      r_buf,
          uint32_t                      chunk,
-         uint32_t*                     stash,      /* [block][segment][STASH_BYTES / 4], first pass only */
+         uint32_t*                     stash,      /* [block][segment][STASH_BYTES / 4] */
          uint32_t*                     seg_cont )  /* table index of byte STASH_BYTES of a longer segment */
 {
     __shared__ uint32_t sBase, sNext, sK0;
@@ -205,7 +201,6 @@ k_walk2( const BlockMeta* __restrict__ meta,
     uint32_t xcc;
     asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"( xcc ) );
     xcc &= WALK_QUEUES - 1;
-    constexpr uint32_t pass = EMIT ? 1u : 0u;
 
     for ( uint32_t attempt = 0; attempt < WALK_QUEUES; ++attempt ) {
         const uint32_t q = ( xcc + attempt ) & ( WALK_QUEUES - 1 );
@@ -215,7 +210,7 @@ k_walk2( const BlockMeta* __restrict__ meta,
         for ( ;; ) {
             __syncthreads();   /* everyone is done with sBase / sNext / sK0 of the previous chunk */
             if ( tid == 0 ) {
-                const uint32_t base = atomicAdd( &plan->ctr[pass][q], chunk );
+                const uint32_t base = atomicAdd( &plan->ctr[q], chunk );
                 sBase = base;
                 sNext = WALK_THREADS;
                 /* last entry k in [qb, qe) with pre[k] <= base */
@@ -251,38 +246,7 @@ k_walk2( const BlockMeta* __restrict__ meta,
                 uint32_t p = j < k0 ? j * stride : origPtr;
                 uint32_t e = tab[p];
                 uint32_t len = 0;
-                if constexpr ( EMIT ) {
-                    const uint32_t off = seg_off[sidx];
-                    if ( off != INVALID_OFF ) {
-                        uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
-                        /* bytes go to descending addresses; whole aligned dwords are written as one store */
-                        uint32_t a = N - 1 - off;      /* address of the next byte */
-                        uint32_t acc = 0, have = 0;    /* bytes collected for the dword that contains a+1.. */
-                        do {
-                            const uint32_t byte = e & 0xFFu;
-                            if ( have == 0 && ( a & 3u ) != 3u ) {
-                                R[a] = (uint8_t)byte;          /* unaligned head: shares its dword with a neighbour */
-                            } else {
-                                acc |= byte << ( 8 * ( a & 3u ) );
-                                ++have;
-                                if ( have == 4 ) {
-                                    *reinterpret_cast<uint32_t*>( R + a ) = acc;
-                                    acc = 0;
-                                    have = 0;
-                                }
-                            }
-                            --a;
-                            ++len;
-                            p = ( e >> 8 ) & LF_MASK;
-                            e = tab[p];
-                        } while ( !( e & MARK ) && len < N );
-                        /* tail: `have` bytes at addresses a+1 .. a+have */
-                        for ( uint32_t z = 0; z < have; ++z ) {
-                            const uint32_t addr = a + 1 + z;
-                            R[addr] = (uint8_t)( acc >> ( 8 * ( addr & 3u ) ) );
-                        }
-                    }
-                } else {
+                {
                     /* measure the segment and keep its first STASH_BYTES bytes (walk order) in the segment's own
                      * 64-B line, 16 bytes per store: k_emit then needs no second gather pass for them */
                     uint4* const line = reinterpret_cast<uint4*>( stash + sidx * ( STASH_BYTES / 4 ) );
