@@ -360,7 +360,7 @@ huff_block( HuffShared&                  sh,
         uint4 D = *reinterpret_cast<const uint4*>( words + myWord );
 
 #ifdef MI355X_BZ2_HUFF_PROFILE
-        uint64_t profSetup = 0, profChain = 0, profCommit = 0, profWindows = 0, profRefresh = 0, profGeneral = 0;
+        uint64_t profSetup = 0, profChain = 0, profCommit = 0, profWindows = 0, profRefresh = 0, profGeneral = 0, profGeneralCycles = 0;
 #define HUFF_PROF_NOW() __builtin_readcyclecounter()
 #endif
         for ( ;; ) {
@@ -584,6 +584,9 @@ huff_block( HuffShared&                  sh,
             fastLeft = fastLeft != 0 ? groupLeft : 0u;
             if ( status != ST_OK ) break;
             pos += consumed;
+#ifdef MI355X_BZ2_HUFF_PROFILE
+            profGeneralCycles += HUFF_PROF_NOW() - profT0;
+#endif
             if ( finished ) { ++nsym; break; }
             if ( invalid ) {
                 /* no code of any length matches at `pos`: the reference runs out of bits first if fewer than the
@@ -595,8 +598,9 @@ huff_block( HuffShared&                  sh,
         }
 #ifdef MI355X_BZ2_HUFF_PROFILE
         if ( lane == 0 && ( b & 15u ) == 0 ) {
-            printf( "[k_huff profile] block %u: %llu fast + %llu general windows, cycles/window: refresh %.1f setup %.1f chain %.1f commit %.1f; bits %llu\n",
-                    b, (unsigned long long)profWindows, (unsigned long long)profGeneral, (double)profRefresh / profWindows, (double)profSetup / profWindows,
+            printf( "[k_huff profile] block %u: %llu fast + %llu general windows (%.0f cycles each), cycles/window: refresh %.1f setup %.1f chain %.1f commit %.1f; bits %llu\n",
+                    b, (unsigned long long)profWindows, (unsigned long long)profGeneral,
+                    (double)profGeneralCycles / ( profGeneral ? profGeneral : 1 ), (double)profRefresh / profWindows, (double)profSetup / profWindows,
                     (double)profChain / profWindows, (double)profCommit / profWindows, (unsigned long long)( posBase + pos - start ) );
         }
 #endif
