@@ -199,13 +199,17 @@ k_find_magic( const uint32_t* __restrict__ words, uint64_t size_bits, uint64_t m
 __device__ __forceinline__ uint64_t
 match_any( uint32_t key, int bits, bool valid )
 {
-    uint64_t mask = __ballot( valid );
+    /* per bit: one ballot, then lanes keep the peers whose bit equals theirs -- mask &= ~( ballot ^ -bit ), an xnor and
+     * an and per half (the obvious `bit ? ballot : ~ballot` costs twice the vector instructions) */
+    const uint64_t all = __ballot( valid );
+    uint32_t lo = (uint32_t)all, hi = (uint32_t)( all >> 32 );
     for ( int b = 0; b < bits; ++b ) {
-        const bool bit = ( key >> b ) & 1u;
-        const uint64_t bal = __ballot( bit );
-        mask &= bit ? bal : ~bal;
+        const uint32_t minusBit = (uint32_t)__builtin_amdgcn_sbfe( (int)key, b, 1 );   /* 0 or 0xFFFFFFFF */
+        const uint64_t bal = __ballot( minusBit != 0 );
+        lo &= ~( (uint32_t)bal ^ minusBit );
+        hi &= ~( (uint32_t)( bal >> 32 ) ^ minusBit );
     }
-    return mask;
+    return ( (uint64_t)hi << 32 ) | lo;
 }
 
 __device__ __forceinline__ uint32_t
