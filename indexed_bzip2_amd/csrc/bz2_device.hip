@@ -617,7 +617,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segCont, segOff, chain );
         TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
                       meta, tab, chain, stash, rbuf );
-        TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf );
+        TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, lcol );
         TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );
         if ( g >= 1 ) {
             HIP_TRY( c, hipEventRecord( c->evGroupDone[g], q ) );

@@ -327,18 +327,35 @@ k_bwt_build( const BlockMeta* __restrict__ meta,
     }
 }
 
-/** Periodic blocks only: R[N-1-k] = R[N-1-(k mod c)] for k >= c (see k_link). */
+/** Blocks whose LF permutation does not have origPtr on an N-cycle (cycle length c < N; see k_link2): the reference's
+ * forward walk over T = LF^-1 (bzip2.hpp:872-879) goes round that cycle for N steps, out[j] = X[j mod c].  The backward
+ * walk here produced Y[k] = X[c-1-k] at R[N-1-k], k < c.  In terms of k that is R[N-1-k] = Y[(k - r) mod c] with
+ * r = N mod c.  Periodic data (valid streams) always has c | N: r = 0 and the first period is simply repeated.  r != 0
+ * only happens for damaged blocks (whose CRC then fails in the reference, too), but the bytes and therefore the
+ * calculated CRC still have to be the reference's: the period is parked in `tmp_buf` (the block's L column, no longer
+ * needed) and laid out again with the shift. */
 __global__ __launch_bounds__( 256 ) void
 k_replicate( const BlockMeta* __restrict__ meta,
-             uint8_t*                      r_buf )
+             uint8_t*                      r_buf,
+             uint8_t*                      tmp_buf )
 {
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok || mt.cycle_len >= mt.n || mt.cycle_len == 0 ) return;
     const uint32_t N = mt.n, c = mt.cycle_len;
     uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
-    for ( uint32_t k = c + threadIdx.x; k < N; k += 256 ) {
-        R[N - 1 - k] = R[N - 1 - ( k % c )];
+    const uint32_t r = N % c;
+    if ( r == 0 ) {
+        for ( uint32_t k = c + threadIdx.x; k < N; k += 256 ) {
+            R[N - 1 - k] = R[N - 1 - ( k % c )];
+        }
+        return;
+    }
+    uint8_t* const Y = tmp_buf + (size_t)b * L_STRIDE;
+    for ( uint32_t k = threadIdx.x; k < c; k += 256 ) Y[k] = R[N - 1 - k];
+    __syncthreads();
+    for ( uint32_t k = threadIdx.x; k < N; k += 256 ) {
+        R[N - 1 - k] = Y[( k % c + c - r ) % c];
     }
 }
 

@@ -239,24 +239,23 @@ huff_block( HuffShared&                  sh,
                 }
                 if ( lane == 0 ) sh.lens[t][s] = (uint8_t)hh;
             }
-        }
-        wave_sync();
-
-        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            /* the reference builds (and checks) the coding of a group before it reads the next group's lengths
+             * (bzip2.hpp:679-683): an over-subscribed set here wins over a bad length further on */
+            wave_sync();
             uint32_t c = 0;
             if ( lane >= 1 && lane <= 20 ) {
                 for ( uint32_t s = 0; s < symCount; ++s ) c += sh.lens[t][s] == lane;
             }
             if ( lane < 24 ) sh.count[t][lane] = c;
             wave_sync();
-            uint32_t minLen = 0, maxLen = 0;
-            for ( uint32_t l = 1; l <= 20; ++l ) {
-                if ( sh.count[t][l] != 0 ) {
-                    if ( minLen == 0 ) minLen = l;
-                    maxLen = l;
-                }
-            }
             {
+                uint32_t minLen = 0, maxLen = 0;
+                for ( uint32_t l = 1; l <= 20; ++l ) {
+                    if ( sh.count[t][l] != 0 ) {
+                        if ( minLen == 0 ) minLen = l;
+                        maxLen = l;
+                    }
+                }
                 uint32_t unused = 1u << minLen;
                 bool bad = false;
                 for ( uint32_t l = minLen; l <= maxLen; ++l ) {
@@ -265,6 +264,17 @@ huff_block( HuffShared&                  sh,
                     unused = ( unused - f ) * 2u;
                 }
                 if ( bad ) FAIL( ST_HUFFMAN_LENGTHS );
+            }
+        }
+        wave_sync();
+
+        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            uint32_t minLen = 0, maxLen = 0;
+            for ( uint32_t l = 1; l <= 20; ++l ) {
+                if ( sh.count[t][l] != 0 ) {
+                    if ( minLen == 0 ) minLen = l;
+                    maxLen = l;
+                }
             }
             if ( lane == 0 ) {
                 uint32_t minCode = 0, sum = 0;

@@ -3,6 +3,7 @@
 Run on the GPU box: python -m pytest tests -m gpu -x -q
 """
 import hashlib
+import os
 
 import pytest
 
@@ -219,3 +220,40 @@ def test_maximal_rle_expansion(native, oracle, dec):
         enc = datagen.compress(raw, 9)
         results = check_blocks(native, oracle, dec, enc, raw, check_stages=False)
         assert max(r["decoded_size"] for r in results) > 40_000_000
+
+
+def test_corruption_fuzz_statuses_match_the_oracle(native, oracle, dec):
+    """Seeded random damage (bit flips in the header / selector / code-length region and in the data, short bursts,
+    truncations) to several kinds of blocks: the GPU must report the same status as the oracle for every block -- the
+    reference throw site for a structural error, CRC mismatch otherwise -- and every other field the reference would
+    have filled in, and must neither hang nor fault."""
+    import numpy as np
+    rng = np.random.default_rng(int(os.environ.get("BZ2_FUZZ_SEED", str(0xC0FFEE)), 0))
+    sources = [datagen.text_like(150_000, 81), datagen.random_bytes(120_000, 82),
+               bytes(rng.integers(0, 7, 200_000, dtype=np.uint8)), b"ab" * 40_000 + datagen.text_like(30_000, 83)]
+    for raw in sources:
+        for level in (1, 9):
+            enc = datagen.compress(raw, level)
+            offs = oracle.find_magic(enc)
+            for case in range(int(os.environ.get("BZ2_FUZZ_CASES", "14"))):
+                bad = bytearray(enc)
+                mode = case % 4
+                if mode == 0:      # header / tables of a random block
+                    o = offs[int(rng.integers(0, len(offs)))] // 8
+                    p = min(len(bad) - 1, o + int(rng.integers(6, 400)))
+                    bad[p] ^= 1 << int(rng.integers(0, 8))
+                elif mode == 1:    # anywhere
+                    p = int(rng.integers(4, len(bad)))
+                    bad[p] ^= 1 << int(rng.integers(0, 8))
+                elif mode == 2:    # burst
+                    p = int(rng.integers(4, max(5, len(bad) - 8)))
+                    bad[p:p + 4] = rng.integers(0, 256, 4, dtype=np.uint8).tobytes()
+                else:              # truncation
+                    bad = bad[:int(rng.integers(5, len(bad)))]
+                bad = bytes(bad)
+                dec.set_input(bad)
+                results, total = dec.decode_batch(offs)
+                for o, r in zip(offs, results):
+                    od, payload = oracle.decode_block(bad, o)
+                    for key in ("status", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc", "is_eos", "is_eof"):
+                        assert r[key] == od[key], (case, mode, o, key, r, od)

@@ -1,7 +1,7 @@
 """CPU suite, part 1: pin the oracle (oracle/bz2_oracle.c) against
   - the reference's own fixtures and raw twins (tests/golden/fixtures, from src/tests/data),
   - golden vectors produced by the REAL reference compiled in the authoring container
-    (tests/golden/reference_vectors.json, made by tools/make_golden.py from oracle/_ref/ref_bz2),
+    (tests/golden/reference_vectors.json, made by tests/golden/make_golden.py from oracle/_ref/ref_bz2),
   - the RUNA/RUNB known-answer table (src/tests/indexed_bzip2/testRunAB.cpp:12-77),
   - the magic-scan known answers (src/tests/core/testBitStringFinder.cpp:119-146),
   - CPython's bz2 module (libbz2) as an independent third decoder,
