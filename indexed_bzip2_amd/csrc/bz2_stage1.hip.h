@@ -132,7 +132,10 @@ huff_block( HuffShared&                  sh,
         const uint64_t lo = br.read( 24 );
         const uint64_t magic = ( hi << 24 ) | lo;
         headerCrc = br.read( 32 );
-        if ( br.eof ) FAIL( ST_EOF );
+        if ( br.eof ) {
+            headerCrc = 0;   /* the reference's read throws before anything is assigned */
+            FAIL( ST_EOF );
+        }
         if ( magic == 0x177245385090ULL ) {
             isEos = 1;
             const uint32_t inByte = (uint32_t)( br.pos & 7 );
@@ -149,7 +152,10 @@ huff_block( HuffShared&                  sh,
         if ( br.eof ) FAIL( ST_EOF );
         if ( randomized ) FAIL( ST_RANDOMIZED );
         origPtr = br.read( 24 );
-        if ( br.eof ) FAIL( ST_EOF );
+        if ( br.eof ) {
+            origPtr = 0;
+            FAIL( ST_EOF );
+        }
         if ( origPtr > MAX_N ) FAIL( ST_ORIGPTR_RANGE );
     }
 

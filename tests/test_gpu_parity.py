@@ -255,5 +255,6 @@ def test_corruption_fuzz_statuses_match_the_oracle(native, oracle, dec):
                 results, total = dec.decode_batch(offs)
                 for o, r in zip(offs, results):
                     od, payload = oracle.decode_block(bad, o)
-                    for key in ("status", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc", "is_eos", "is_eof"):
+                    for key in ("status", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc", "is_eos", "is_eof",
+                                "orig_ptr", "bwt_length", "n_symbols"):
                         assert r[key] == od[key], (case, mode, o, key, r, od)
