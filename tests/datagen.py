@@ -92,3 +92,46 @@ def corpus_small():
 
 def multistream(parts, level=9):
     return b"".join(bz2.compress(p, level) for p in parts)
+
+
+def damaged_corpus(cases=48, seed=0xDA3A6ED):
+    """Deterministic damaged inputs: name -> (bytes, [block bit offsets of the UNDAMAGED stream that still lie inside]).
+    Bit flips in the header / tables of a block, anywhere, 4-byte bursts, truncations, over four kinds of data and
+    levels 1 and 9.  The golden vectors hold what the real reference does with every (file, offset)."""
+    import numpy as np
+    g = np.random.default_rng(seed)
+    sources = [text_like(120_000, 91), random_bytes(90_000, 92), bytes(g.integers(0, 5, 150_000, dtype=np.uint8)),
+               b"abc" * 30_000]
+    out = {}
+    for case in range(cases):
+        raw = sources[case % len(sources)]
+        enc = bytearray(compress(raw, 1 if case % 3 else 9))
+        offs = _block_offsets(bytes(enc))
+        mode = case % 4
+        if mode == 0:
+            o = offs[int(g.integers(0, len(offs)))] // 8
+            p = min(len(enc) - 1, o + int(g.integers(6, 400)))
+            enc[p] ^= 1 << int(g.integers(0, 8))
+        elif mode == 1:
+            enc[int(g.integers(4, len(enc)))] ^= 1 << int(g.integers(0, 8))
+        elif mode == 2:
+            p = int(g.integers(4, max(5, len(enc) - 8)))
+            enc[p:p + 4] = g.integers(0, 256, 4, dtype=np.uint8).tobytes()
+        else:
+            enc = enc[:int(g.integers(5, len(enc)))]
+        out[f"damaged-{case:02d}"] = (bytes(enc), [o for o in offs if o + 48 <= len(enc) * 8])
+    return out
+
+
+def _block_offsets(enc):
+    """Bit offsets of the block magic 0x314159265359 (plain Python/numpy, independent of oracle and product)."""
+    import numpy as np
+    a = np.frombuffer(enc, dtype=np.uint8)
+    bits = np.unpackbits(a)
+    magic = np.unpackbits(np.frombuffer(bytes.fromhex("314159265359"), dtype=np.uint8))
+    # candidates: positions where the first 16 magic bits match, then verify
+    n = len(bits) - 48 + 1
+    if n <= 0:
+        return []
+    cand = np.flatnonzero(np.lib.stride_tricks.sliding_window_view(bits, 8)[:n, :].dot(1 << np.arange(7, -1, -1)) == 0x31)
+    return [int(c) for c in cand if c + 48 <= len(bits) and np.array_equal(bits[c:c + 48], magic)]

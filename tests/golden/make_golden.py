@@ -47,7 +47,7 @@ def corrupt_cases():
 
 def main():
     assert O.ref_available(), "build oracle/_ref first: make -C oracle ref"
-    golden = {"fixtures": {}, "generated": {}, "multistream": {}, "probes": {}}
+    golden = {"fixtures": {}, "generated": {}, "multistream": {}, "probes": {}, "damaged": {}}
     for f in sorted(os.listdir(FIX)):
         if f.endswith(".bz2"):
             p = os.path.join(FIX, f)
@@ -76,6 +76,22 @@ def main():
             golden["probes"][name] = {"enc_sha256": hashlib.sha256(data).hexdigest(), "verdict": verdict[0],
                                       "exception": verdict[1] if verdict[0] == "EXC" else "",
                                       "what": " ".join(out.split()[2:])[:160] if verdict[0] == "EXC" else ""}
+        # damaged corpus: what the reference does with every block offset of every damaged file
+        golden["damaged"] = {}
+        for name, (data, offs) in sorted(datagen.damaged_corpus().items()):
+            open(p, "wb").write(data)
+            entry = {"enc_sha256": hashlib.sha256(data).hexdigest(), "blocks": {}}
+            for off in offs:
+                out = O.ref_run("probe", p, off).strip()
+                if out.startswith("EXC"):
+                    parts = out.split(" ", 2)
+                    entry["blocks"][str(off)] = {"verdict": "EXC", "exception": parts[1],
+                                                 "what": (parts[2] if len(parts) > 2 else "")[:160]}
+                else:
+                    f = out.split()
+                    entry["blocks"][str(off)] = {"verdict": "OK", "exception": "", "what": "", "size": int(f[2]),
+                                                 "header_crc": int(f[3], 16), "calc_crc": int(f[4], 16), "decoded": int(f[5])}
+            golden["damaged"][name] = entry
     with open(OUT, "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

@@ -258,3 +258,15 @@ def test_corruption_fuzz_statuses_match_the_oracle(native, oracle, dec):
                     for key in ("status", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc", "is_eos", "is_eof",
                                 "orig_ptr", "bwt_length", "n_symbols"):
                         assert r[key] == od[key], (case, mode, o, key, r, od)
+
+
+def test_damaged_blocks_vs_reference_vectors(native, dec):
+    """The GPU against the REAL reference directly (no oracle in between): 60 blocks of 48 damaged files, verdicts and
+    calculated CRCs recorded from oracle/_ref/ref_bz2 in tests/golden/reference_vectors.json."""
+    from test_oracle import _check_damaged
+
+    def decode_block(data, off):
+        dec.set_input(data)
+        results, _total = dec.decode_batch([off])
+        return results[0]
+    _check_damaged(decode_block)

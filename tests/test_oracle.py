@@ -226,3 +226,30 @@ def test_live_reference_agrees(oracle, tmp_path):
         d, payload = oracle.decode_block(enc, int(off))
         assert (d["encoded_size_bits"], d["header_crc"], d["computed_crc"], d["decoded_size"]) == \
                (int(size), int(hcrc, 16), int(ccrc, 16), int(dsize))
+
+
+def _check_damaged(decode_block):
+    """Every (damaged file, block offset) of tests/golden/reference_vectors.json["damaged"] -- verdicts of the REAL
+    reference (oracle/_ref/ref_bz2 probe): status, and the calculated CRC even where the block fails its CRC."""
+    corpus = datagen.damaged_corpus()
+    checked = 0
+    for name, (data, offs) in sorted(corpus.items()):
+        gold = GOLDEN["damaged"][name]
+        assert hashlib.sha256(data).hexdigest() == gold["enc_sha256"], "generator drifted: rerun tests/golden/make_golden.py"
+        assert sorted(int(o) for o in gold["blocks"]) == sorted(offs)
+        for off in offs:
+            ref = gold["blocks"][str(off)]
+            d = decode_block(data, off)
+            assert d["status"] == expected_status(ref), (name, off, d, ref)
+            if ref["verdict"] == "OK" and not d["is_eos"]:
+                assert (d["decoded_size"], d["header_crc"], d["computed_crc"], d["encoded_size_bits"]) == \
+                       (ref["decoded"], ref["header_crc"], ref["calc_crc"], ref["size"]), (name, off, d, ref)
+            if "Calculated CRC" in ref["what"]:
+                words = ref["what"].split()
+                assert (int(words[2], 16), int(words[-1], 16)) == (d["computed_crc"], d["header_crc"]), (name, off, d, ref)
+            checked += 1
+    assert checked == 60
+
+
+def test_damaged_blocks_vs_reference(oracle):
+    _check_damaged(lambda data, off: oracle.decode_block(data, off)[0])
