@@ -135,3 +135,60 @@ def _block_offsets(enc):
         return []
     cand = np.flatnonzero(np.lib.stride_tricks.sliding_window_view(bits, 8)[:n, :].dot(1 << np.arange(7, -1, -1)) == 0x31)
     return [int(c) for c in cand if c + 48 <= len(bits) and np.array_equal(bits[c:c + 48], magic)]
+
+
+def exotic_streams():
+    """Valid streams no libbz2 writes (tests/bz2enc.py): name -> (raw, encoded).  Codes of up to 20 bits on rare and on
+    FREQUENT symbols, 2..6 tables with scrambled selectors, symbols that are declared but never used, surplus
+    selectors.  (libbz2 limits code lengths to 17 and never declares unused symbols.)"""
+    import random
+    import bz2enc
+    r = random.Random(0xE807)
+    values = bytes(r.sample(range(256), 19))                       # alphabet 19 + 2 = 21: lengths 1..19, 20, 20
+    skewed = bytes(r.choices(values, weights=[2.0 ** -i for i in range(19)], k=3000))
+    flat = bytes(r.choices(values, k=2500))
+
+    def rarest_first(t, alphabet, freq):
+        ranking = sorted(range(alphabet), key=lambda s: (freq[s], s))
+        return bz2enc.skewed_lengths(alphabet, ranking)
+
+    def rotating(t, alphabet, freq):
+        ranking = sorted(range(alphabet), key=lambda s: (-freq[s], s))
+        ranking = ranking[t:] + ranking[:t]                        # a different code per table
+        return bz2enc.skewed_lengths(alphabet, ranking)
+    wide = bytes(r.choices(range(60), k=5000))
+    out = {
+        "skew20-2tables": (skewed, bz2enc.encode_block(skewed, n_groups=2)),
+        "skew20-frequent-long-6tables": (flat, bz2enc.encode_block(flat, n_groups=6, length_fn=rarest_first,
+                                                                  selector_fn=lambda g: (g * 5 + 1) % 6)),
+        "rotating-codes-5tables": (skewed, bz2enc.encode_block(skewed, level=1, n_groups=5, length_fn=rotating,
+                                                                selector_fn=lambda g: (g * 3) % 5)),
+        "alphabet62-deep-tail": (wide, bz2enc.encode_block(wide, n_groups=3)),
+        "declared-unused-extra-selectors": (skewed, bz2enc.encode_block(skewed, n_groups=4, declare_unused=(1, 200, 255),
+                                                                         extra_selectors=7)),
+        "tiny": (b"\x00", bz2enc.encode_block(b"\x00", n_groups=2)),
+    }
+    return out
+
+
+def faulty_streams():
+    """Structurally invalid blocks, one per reference throw site that random damage rarely reaches (tests/bz2enc.py with
+    deliberate violations): name -> (encoded, status).  The statuses are those of the REAL reference for exactly these
+    streams (oracle/_ref/ref_bz2 probe, exception texts in the comments)."""
+    import bz2enc
+    data = bytes(range(30)) * 40
+    alphabet = 32                                   # 30 byte values + RUNA/RUNB ... end-of-block = symbol 31
+
+    def enc(**faults):
+        return bz2enc.encode_block(data, n_groups=3, faults=faults)
+    return {
+        "randomized-bit": (enc(randomized=1), 3),                  # "deprecated isRandomized bit is not supported"
+        "origptr-900001": (enc(orig_ptr=900001), 4),               # "origPtr 900001 is larger than buffer size: 900000"
+        "origptr-equals-n": (enc(orig_ptr=len(bz2enc.rle1(data))), 14),   # "[BZip2 block data] origPtr error 1200"
+        "group-count-1": (enc(n_groups_field=1), 5),               # "Invalid Huffman coding group count 1"
+        "group-count-7": (enc(n_groups_field=7), 5),
+        "selector-count-0": (enc(n_selectors_field=0), 6),         # "The number of selectors 0 is invalid"
+        "selectors-run-out": (enc(drop_selectors=2), 10),          # "selector 2 out of maximum range 2"
+        "run-overflow": (enc(symbols=[1] * 22 + [5, alphabet - 1]), 12),        # "dbufCount + hh 8388606 > 900000"
+        "data-overflow": (enc(symbols=[2, 2] * 450_001 + [alphabet - 1]), 13),  # "dbufCount 900000 > 900000 dbufSize"
+    }

@@ -270,3 +270,18 @@ def test_damaged_blocks_vs_reference_vectors(native, dec):
         results, _total = dec.decode_batch([off])
         return results[0]
     _check_damaged(decode_block)
+
+
+@pytest.mark.parametrize("name", sorted(datagen.exotic_streams()))
+def test_exotic_valid_streams(native, oracle, dec, name):
+    """20-bit Huffman codes (also on frequent symbols: every window goes through the long-code path), 2..6 tables with
+    scrambled selectors, declared-but-unused symbols, surplus selectors -- valid streams libbz2 never writes."""
+    raw, enc = datagen.exotic_streams()[name]
+    check_blocks(native, oracle, dec, enc, raw)
+
+
+@pytest.mark.parametrize("name", sorted(datagen.faulty_streams()))
+def test_faulty_streams_one_per_throw_site(native, oracle, dec, name):
+    enc, status = datagen.faulty_streams()[name]
+    results = check_blocks(native, oracle, dec, enc, check_stages=False)
+    assert results[0]["status"] == status

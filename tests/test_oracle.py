@@ -253,3 +253,36 @@ def _check_damaged(decode_block):
 
 def test_damaged_blocks_vs_reference(oracle):
     _check_damaged(lambda data, off: oracle.decode_block(data, off)[0])
+
+
+def test_exotic_valid_streams(oracle):
+    """Streams from tests/bz2enc.py (20-bit codes, 2..6 tables, declared-but-unused symbols, surplus selectors):
+    libbz2 (CPython bz2) and the oracle must both decode them; the real reference accepted the same streams when this
+    test was written (oracle/_ref/ref_bz2 probe)."""
+    import bz2
+    for name, (raw, enc) in sorted(datagen.exotic_streams().items()):
+        assert bz2.decompress(enc) == raw, name
+        d, payload = oracle.decode_block(enc, 32)
+        assert d["status"] == 0 and payload == raw and d["computed_crc"] == d["header_crc"], (name, d)
+        st, out, block_map, garbage = oracle.decode_file(enc)
+        assert st == 0 and out == raw and not garbage
+        if oracle.ref_available():
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".bz2") as f:
+                f.write(enc)
+                f.flush()
+                assert oracle.ref_run("probe", f.name, 32).startswith("OK"), name
+
+
+def test_faulty_streams_one_per_throw_site(oracle):
+    """tests/bz2enc.py with deliberate violations; expected statuses recorded from the real reference."""
+    for name, (enc, status) in sorted(datagen.faulty_streams().items()):
+        d, _ = oracle.decode_block(enc, 32)
+        assert d["status"] == status, (name, d)
+        if oracle.ref_available():
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".bz2") as f:
+                f.write(enc)
+                f.flush()
+                out = oracle.ref_run("probe", f.name, 32).strip().split(" ", 2)
+                assert out[0] == "EXC" and expected_status({"verdict": "EXC", "exception": out[1], "what": out[2]}) == status
