@@ -285,3 +285,37 @@ def test_faulty_streams_one_per_throw_site(native, oracle, dec, name):
     enc, status = datagen.faulty_streams()[name]
     results = check_blocks(native, oracle, dec, enc, check_stages=False)
     assert results[0]["status"] == status
+
+
+def test_batch_of_shuffled_duplicated_and_bogus_offsets(native, oracle, dec):
+    """decode_batch sorts blocks into cost groups on several streams internally; results and the ragged output must
+    still follow the caller's order -- for shuffled offsets, duplicates, end-of-stream offsets and offsets that are no
+    block at all, with enough blocks (>= 64) for the grouping to kick in."""
+    import numpy as np
+    parts = [datagen.text_like(900_000, 121), datagen.random_bytes(500_000, 122), datagen.runs(700_000, 123),
+             bytes(np.random.default_rng(5).integers(0, 4, 600_000, dtype=np.uint8))]
+    enc = datagen.multistream(parts, 1)                      # ~30 blocks of 100 kB, four streams
+    blocks = oracle.find_magic(enc)
+    eos = oracle.find_magic(enc, oracle.MAGIC_EOS)
+    rng = np.random.default_rng(77)
+    offsets = list(blocks) * 3 + list(eos) + [blocks[2] + 1, blocks[5] + 13, len(enc) * 8 - 3, len(enc) * 8 + 100]
+    rng.shuffle(offsets)
+    offsets = [int(o) for o in offsets]
+    assert len(offsets) >= 64
+    dec.set_input(enc)
+    results, total = dec.decode_batch(offsets)
+    out = dec.copy_output(0, total)
+    single = {}
+    pos = 0
+    for o, r in zip(offsets, results):
+        if o not in single:
+            single[o] = oracle.decode_block(enc, o)
+        d, payload = single[o]
+        for key in ("status", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc", "is_eos", "is_eof"):
+            assert r[key] == d[key], (o, key, r, d)
+        assert r["encoded_offset_bits"] == o
+        if d["status"] == 0 and not d["is_eos"]:
+            assert r["data_offset"] == pos
+            assert out[pos:pos + r["decoded_size"]] == payload, o
+            pos += r["decoded_size"]
+    assert pos == total
