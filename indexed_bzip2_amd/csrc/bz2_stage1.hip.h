@@ -772,6 +772,37 @@ struct SymStream
     }
 };
 
+/** Calls step( symbol ) for symbols [begin, end) of a lane's chunk, eight symbols per 16-byte load with the extraction
+ * unrolled (static shifts instead of SymStream's dynamic ones); the next load is in flight while a group is processed.
+ * step returns false to stop early. */
+template<typename Step>
+__device__ __forceinline__ void
+for_symbols( const uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
+{
+    uint32_t i = begin;
+    for ( ; i < end && ( i & 7u ) != 0; ++i ) {
+        if ( !step( (uint32_t)sym[i] ) ) return;
+    }
+    if ( i + 8 <= end ) {
+        uint4 next = *reinterpret_cast<const uint4*>( sym + i );
+        for ( ; i + 8 <= end; i += 8 ) {
+            const uint4 v = next;
+            next = *reinterpret_cast<const uint4*>( sym + i + 8 );   /* the symbol buffer is padded past n */
+            if ( !step( v.x & 0xFFFFu ) ) return;
+            if ( !step( v.x >> 16 ) ) return;
+            if ( !step( v.y & 0xFFFFu ) ) return;
+            if ( !step( v.y >> 16 ) ) return;
+            if ( !step( v.z & 0xFFFFu ) ) return;
+            if ( !step( v.z >> 16 ) ) return;
+            if ( !step( v.w & 0xFFFFu ) ) return;
+            if ( !step( v.w >> 16 ) ) return;
+        }
+    }
+    for ( ; i < end; ++i ) {
+        if ( !step( (uint32_t)sym[i] ) ) return;
+    }
+}
+
 /** Per-lane write combiner for a sequential byte stream: whole aligned dwords go out as one store (byte-granular
  * scattered stores cost a full write request each: 43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE).  Only the
  * unaligned head and the tail of a lane's range, which share a dword with the neighbouring lane, are written bytewise. */
@@ -877,10 +908,7 @@ k_mtf( BlockMeta* __restrict__       meta,
     unsigned long long count = 0;
     {
         uint32_t runPos = 0, hh = 0;
-        SymStream stream;
-        stream.init( sym, begin );
-        for ( uint32_t i = begin; i < end; ++i ) {
-            const uint32_t s = stream.get( i );
+        for_symbols( sym, begin, end, [&] ( uint32_t s ) {
             if ( s <= 1 ) {
                 if ( runPos == 0 ) { runPos = 1; hh = 0; }
                 hh += runPos << s;
@@ -890,7 +918,8 @@ k_mtf( BlockMeta* __restrict__       meta,
                 mtf_lane_move( mine, permRows, s - 1 );
                 ++count;
             }
-        }
+            return true;
+        } );
         if ( runPos != 0 ) count += hh;
     }
     /* exclusive prefix sum of the chunk sizes */
@@ -927,24 +956,22 @@ k_mtf( BlockMeta* __restrict__       meta,
         ByteSink sink{ L, prefix, 0, 0 };
         uint32_t runPos = 0, hh = 0;
         uint32_t err = 0;
-        SymStream stream;
-        stream.init( sym, begin );
-        for ( uint32_t i = begin; i < end && err == 0; ++i ) {
-            const uint32_t s = stream.get( i );
+        for_symbols( sym, begin, end, [&] ( uint32_t s ) {
             if ( s <= 1 ) {
                 if ( runPos == 0 ) { runPos = 1; hh = 0; }
                 hh += runPos << s;
                 runPos <<= 1;
-                continue;
+                return true;
             }
             if ( runPos != 0 ) {
                 runPos = 0;
-                if ( sink.o + hh > MAX_N ) { err = ST_RUN_OVERFLOW; break; }
+                if ( sink.o + hh > MAX_N ) { err = ST_RUN_OVERFLOW; return false; }
                 sink.fill( reinterpret_cast<const uint8_t*>( mine )[0], hh );
             }
-            if ( sink.o >= MAX_N ) { err = ST_DATA_OVERFLOW; break; }
+            if ( sink.o >= MAX_N ) { err = ST_DATA_OVERFLOW; return false; }
             sink.put( mtf_lane_move( mine, permRows, s - 1 ) );
-        }
+            return true;
+        } );
         /* a run that is still open where the Huffman stage FAILED is never flushed by the reference */
         if ( err == 0 && runPos != 0 && ( end < n || hm.status == ST_OK ) ) {
             if ( sink.o + hh > MAX_N ) {
