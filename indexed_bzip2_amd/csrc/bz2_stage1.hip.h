@@ -809,31 +809,30 @@ for_symbols( const uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
 struct ByteSink
 {
     uint8_t* base;
-    unsigned long long o;   /* next byte position */
-    uint32_t acc;
-    uint32_t have;          /* bytes collected in acc (positions o-have .. o-1, o-have is dword aligned) */
+    uint32_t lo;    /* first byte position of this lane's range */
+    uint32_t o;     /* next byte position */
+    uint32_t acc;   /* bytes of the dword that contains o, at their place */
 
     __device__ __forceinline__ void
     put( uint32_t byte )
     {
-        if ( have == 0 && ( o & 3u ) != 0 ) {
-            base[o++] = (uint8_t)byte;
-            return;
-        }
-        acc |= byte << ( 8 * have );
-        ++have;
+        acc |= byte << ( 8 * ( o & 3u ) );
         ++o;
-        if ( have == 4 ) {
-            *reinterpret_cast<uint32_t*>( base + o - 4 ) = acc;
+        if ( ( o & 3u ) == 0 ) {
+            if ( o - 4 >= lo ) {
+                *reinterpret_cast<uint32_t*>( base + o - 4 ) = acc;
+            } else {
+                /* the dword in which the range starts belongs to the previous lane as well: bytes */
+                for ( uint32_t k = lo; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
+            }
             acc = 0;
-            have = 0;
         }
     }
 
     __device__ __forceinline__ void
     fill( uint32_t byte, uint32_t count )
     {
-        while ( count != 0 && ( have != 0 || ( o & 3u ) != 0 ) ) { put( byte ); --count; }
+        while ( count != 0 && ( o & 3u ) != 0 ) { put( byte ); --count; }
         const uint32_t word = byte * 0x01010101u;
         for ( uint32_t k = count >> 2; k != 0; --k ) {
             *reinterpret_cast<uint32_t*>( base + o ) = word;
@@ -845,8 +844,9 @@ struct ByteSink
     __device__ __forceinline__ void
     flush()
     {
-        for ( uint32_t k = 0; k < have; ++k ) base[o - have + k] = (uint8_t)( acc >> ( 8 * k ) );
-        have = 0;
+        /* the last, incomplete dword (shared with the next lane) */
+        const uint32_t first = ( o & ~3u ) > lo ? ( o & ~3u ) : lo;
+        for ( uint32_t k = first; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
         acc = 0;
     }
 };
@@ -953,7 +953,10 @@ k_mtf( BlockMeta* __restrict__       meta,
 
     /* ---- pass B: replay with the true start list, write the L column ---- */
     {
-        ByteSink sink{ L, prefix, 0, 0 };
+        /* positions are 32-bit: a start beyond the buffer (only possible for damaged data, whose runs can add up to
+         * anything) is clamped -- that lane then reports the overflow at its first symbol, an earlier lane wins anyway */
+        const uint32_t startAt = prefix < MAX_N ? (uint32_t)prefix : MAX_N;
+        ByteSink sink{ L, startAt, startAt, 0 };
         uint32_t runPos = 0, hh = 0;
         uint32_t err = 0;
         for_symbols( sym, begin, end, [&] ( uint32_t s ) {
