@@ -308,22 +308,30 @@ k_bwt_build( const BlockMeta* __restrict__ meta,
      * would cost more than the ranking itself) */
     uint32_t rem = ( begin + lane ) % stride;
     const uint32_t remStep = 64u % stride;
-    for ( uint32_t base = begin; base < end; base += 64 ) {
-        const uint32_t i = base + lane;
-        const bool valid = i < end;
-        const uint32_t key = valid ? L[i] : 0u;
-        const uint64_t same = match_any( key, 8, valid );
-        const uint32_t rank = popc_below( same, lane );
-        uint32_t basePos = 0;
-        if ( valid ) basePos = hist[wave][key];
-        if ( valid ) {
-            const uint32_t lf = basePos + rank;
-            const bool mark = ( rem == 0 ) || ( i == origPtr );
-            tab[i] = ( lf << 8 ) | key | ( mark ? MARK : 0u );
-            if ( rank == 0 ) hist[wave][key] = basePos + (uint32_t)__popcll( same );
+    /* four steps per trip: their bytes are loaded together, so the ranking of one step hides the load latency of the
+     * next ones instead of every step waiting for its own byte (the L buffer is padded: reading past `end` is fine) */
+    for ( uint32_t base4 = begin; base4 < end; base4 += 256 ) {
+        uint32_t keys[4];
+#pragma unroll
+        for ( uint32_t u = 0; u < 4; ++u ) keys[u] = L[base4 + 64 * u + lane];
+#pragma unroll
+        for ( uint32_t u = 0; u < 4; ++u ) {
+            const uint32_t i = base4 + 64 * u + lane;
+            const bool valid = i < end;
+            const uint32_t key = valid ? keys[u] : 0u;
+            const uint64_t same = match_any( key, 8, valid );
+            const uint32_t rank = popc_below( same, lane );
+            uint32_t basePos = 0;
+            if ( valid ) basePos = hist[wave][key];
+            if ( valid ) {
+                const uint32_t lf = basePos + rank;
+                const bool mark = ( rem == 0 ) || ( i == origPtr );
+                tab[i] = ( lf << 8 ) | key | ( mark ? MARK : 0u );
+                if ( rank == 0 ) hist[wave][key] = basePos + (uint32_t)__popcll( same );
+            }
+            rem += remStep;
+            if ( rem >= stride ) rem -= stride;
         }
-        rem += remStep;
-        if ( rem >= stride ) rem -= stride;
     }
 }
 
