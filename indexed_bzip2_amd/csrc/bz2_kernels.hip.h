@@ -412,9 +412,33 @@ k_rle( BlockMeta*                   meta,
     __shared__ uint64_t wsum[RLE_THREADS / 64];
     __shared__ uint32_t carryFn;     /* state before the tile (as a constant function value) */
     __shared__ uint64_t carrySum;
+    /* Eight bytes at a time: fnTab[e] = transition function of eight bytes whose equal-to-predecessor bits are e;
+     * cmTab[k][e] = which of them are repeat counts when the group is entered in state k (low 8 bits) and the state
+     * behind it (bits 8-10).  A full 32-byte chunk then costs four look-ups and three compositions instead of 32 x 5
+     * state steps. */
+    __shared__ uint16_t fnTab[256];
+    __shared__ uint16_t cmTab[5][256];
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok ) return;
+    if ( threadIdx.x < 256 ) {
+        const uint32_t e = threadIdx.x;
+        uint32_t t[5] = { 0, 1, 2, 3, 4 };
+        for ( uint32_t q = 0; q < 8; ++q ) {
+            const bool eq = ( e >> q ) & 1u;
+            for ( uint32_t k = 0; k < 5; ++k ) t[k] = rle_step( t[k], eq );
+        }
+        fnTab[e] = (uint16_t)( t[0] | ( t[1] << 3 ) | ( t[2] << 6 ) | ( t[3] << 9 ) | ( t[4] << 12 ) );
+        for ( uint32_t k = 0; k < 5; ++k ) {
+            uint32_t state = k, counts = 0;
+            for ( uint32_t q = 0; q < 8; ++q ) {
+                if ( state == 4 ) counts |= 1u << q;
+                state = rle_step( state, ( e >> q ) & 1u );
+            }
+            cmTab[k][e] = (uint16_t)( counts | ( state << 8 ) );
+        }
+    }
+    __syncthreads();
     const uint32_t N = mt.n;
     const uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
     uint8_t* const dst = WRITE ? out + mt.out_off : nullptr;
@@ -438,7 +462,20 @@ k_rle( BlockMeta*                   meta,
         }
         /* eq mask of my bytes */
         uint32_t eqMask = 0;
-        {
+        const bool full = nb == RLE_BYTES_PER_THREAD;
+        if ( full ) {
+            /* four bytes per step: a byte of d is zero where the byte equals its predecessor */
+            uint32_t before = prev << 24;   /* prev == 0x100 (no predecessor) turns into 0: handled below */
+#pragma unroll
+            for ( uint32_t j = 0; j < RLE_BYTES_PER_THREAD / 4; ++j ) {
+                const uint32_t d = wv[j] ^ __builtin_amdgcn_alignbit( wv[j], before, 24 );
+                const uint32_t nonZero = ( ( ( d & 0x7F7F7F7Fu ) + 0x7F7F7F7Fu ) | d ) & 0x80808080u;
+                const uint32_t e = ( ~nonZero >> 7 ) & 0x01010101u;
+                eqMask |= ( ( e * 0x01020408u ) >> 24 & 0xFu ) << ( 4 * j );
+                before = wv[j];
+            }
+            if ( prev > 0xFFu ) eqMask &= ~1u;   /* first byte of the block has no predecessor */
+        } else {
             uint32_t p = prev;
             _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
@@ -448,7 +485,10 @@ k_rle( BlockMeta*                   meta,
         }
         /* my chunk's transition function: 5 tracks */
         uint32_t fn = FN_IDENTITY;
-        if ( nb > 0 ) {
+        if ( full ) {
+            fn = fn_compose( fn_compose( fnTab[eqMask & 0xFFu], fnTab[( eqMask >> 8 ) & 0xFFu] ),
+                             fn_compose( fnTab[( eqMask >> 16 ) & 0xFFu], fnTab[eqMask >> 24] ) );
+        } else if ( nb > 0 ) {
             uint32_t t0 = 0, t1 = 1, t2 = 2, t3 = 3, t4 = 4;
             _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const bool eq = ( eqMask >> q ) & 1u;
@@ -475,7 +515,29 @@ k_rle( BlockMeta*                   meta,
         /* output size of my chunk with the true entry state; remember per-byte class */
         uint32_t mySize = 0;
         uint32_t countMask = 0;
-        {
+        if ( full ) {
+            uint32_t r = cmTab[k][eqMask & 0xFFu];
+            countMask = r & 0xFFu;
+            r = cmTab[r >> 8][( eqMask >> 8 ) & 0xFFu];
+            countMask |= ( r & 0xFFu ) << 8;
+            r = cmTab[r >> 8][( eqMask >> 16 ) & 0xFFu];
+            countMask |= ( r & 0xFFu ) << 16;
+            r = cmTab[r >> 8][eqMask >> 24];
+            countMask |= ( r & 0xFFu ) << 24;
+            mySize = RLE_BYTES_PER_THREAD - (uint32_t)__popc( countMask );
+            if ( countMask != 0 ) {
+#pragma unroll
+                for ( uint32_t j = 0; j < RLE_BYTES_PER_THREAD / 4; ++j ) {
+                    const uint32_t four = ( countMask >> ( 4 * j ) ) & 0xFu;
+                    if ( four != 0 ) {
+#pragma unroll
+                        for ( uint32_t z = 0; z < 4; ++z ) {
+                            if ( ( four >> z ) & 1u ) mySize += ( wv[j] >> ( 8 * z ) ) & 0xFFu;
+                        }
+                    }
+                }
+            }
+        } else {
             uint32_t kk = k;
             _Pragma( "unroll" ) for ( uint32_t q = 0; q < RLE_BYTES_PER_THREAD; ++q ) { if ( q >= nb ) break;
                 const uint32_t c = ( wv[q >> 2] >> ( 8 * ( q & 3 ) ) ) & 0xFFu;
