@@ -125,6 +125,10 @@ const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
  * Replaces the BitReader/SharedFileReader clone + pread of BZ2BlockFetcher.hpp:89-90. */
 int mi355x_bz2_set_input_host( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
 int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, uint64_t size );
+/* Several contexts over ONE resident copy of the input (the reader keeps two contexts to overlap consecutive batches):
+ * `ctx` decodes from the bytes `from` made resident.  Nothing is copied; `from` must outlive `ctx`'s use of them and
+ * keep its input unchanged.  Both contexts must be on the same device. */
+int mi355x_bz2_share_input( mi355x_bz2_ctx* ctx, mi355x_bz2_ctx* from );
 
 /* Decode n_blocks independent blocks whose magic starts at block_bit_offsets[i] (from the finder or the index).
  * = n calls of BZ2BlockFetcher::decodeBlock (BZ2BlockFetcher.hpp:85-138).  An offset pointing at an EOS magic

@@ -104,6 +104,7 @@ SYMBOLS = [
     ("mi355x_bz2_debug_copy_stage", ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_int, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_find_magic", ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _u64p,
                                                  ctypes.c_uint64, ctypes.c_uint32]),
+    ("mi355x_bz2_share_input", ctypes.c_int, [_vp, _vp]),
     ("mi355x_bz2_find_magic_device", ctypes.c_int, [_vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, _u64p]),
     ("mi355x_bz2_read_stream_header", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
     ("mi355x_bz2_reader_open_path", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
@@ -208,6 +209,11 @@ class Decoder:
     def set_input_device(self, ptr: int, size: int, keepalive=None):
         self._input_ref = keepalive
         self._check(lib().mi355x_bz2_set_input_device(self._h, ptr, size))
+
+    def share_input(self, other: "Decoder"):
+        """Decode from the bytes `other` made resident (no copy); `other` is kept alive."""
+        self._input_ref = other
+        self._check(lib().mi355x_bz2_share_input(self._h, other._h))
 
     def decode_batch(self, offsets):
         n = len(offsets)

@@ -449,6 +449,24 @@ mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_
 }
 
 int
+mi355x_bz2_share_input( mi355x_bz2_ctx* c, mi355x_bz2_ctx* from )
+{
+    if ( c == nullptr || from == nullptr || c == from ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex, from->mutex );
+    if ( from->dIn == nullptr || c->device != from->device ) {
+        c->lastError = "share_input: the other context has no input or lives on another device";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "share_input: a batch is in flight";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    c->dIn = from->dIn;      /* not owned: mi355x_bz2_destroy frees dInOwned only */
+    c->inSize = from->inSize;
+    return MI355X_BZ2_OK;
+}
+
+int
 mi355x_bz2_decode_batch( mi355x_bz2_ctx* c, const uint64_t* offsets, uint32_t n,
                          mi355x_bz2_block_result* results, uint64_t* totalDecoded )
 {

@@ -18,12 +18,14 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <future>
 #include <iostream>
+#include <list>
 #include <memory>
 #include <queue>
 #include <sstream>
@@ -257,7 +259,9 @@ public:
             int rc = mi355x_bz2_create( &config, &ctx );
             std::string detail;
             if ( rc == MI355X_BZ2_OK ) {
-                rc = mi355x_bz2_set_input_host( ctx, m_source->bytes(), m_source->size() );
+                /* one resident copy of the compressed file for all contexts */
+                rc = m_ctxs.empty() ? mi355x_bz2_set_input_host( ctx, m_source->bytes(), m_source->size() )
+                                    : mi355x_bz2_share_input( ctx, m_ctxs.front() );
                 if ( rc != MI355X_BZ2_OK ) {
                     detail = mi355x_bz2_last_error( ctx );
                     mi355x_bz2_destroy( ctx );
@@ -269,6 +273,20 @@ public:
                 fail( rc, detail );
             }
             m_ctxs.push_back( ctx );
+        }
+        /* The file is resident on the GPU now: let it find the block magics too (k_find_magic, a few ms per GB).  The
+         * host finder threads (ParallelBitStringFinder's job, ~1.3 GB/s of compressed data on eight cores) would
+         * otherwise pace the whole reader.  Same offsets, delivered at once; if the scan cannot be used (more matches
+         * than its result buffer holds) the host threads take over as before. */
+        if ( !m_blockFinder->finalized() ) {
+            /* the scan keeps up to 2^20 matches (>= 100 GB of level-9 data) and reports MI355X_BZ2_ERR_OUTPUT_CAPACITY beyond */
+            std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
+            uint64_t found = 0;
+            if ( ( mi355x_bz2_find_magic_device( m_ctxs.front(), MI355X_BZ2_MAGIC_BLOCK, offsets.data(), offsets.size(),
+                                                 &found ) == MI355X_BZ2_OK ) && ( found <= offsets.size() ) ) {
+                offsets.resize( found );
+                m_blockFinder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
+            }
         }
         for ( auto* const ctx : m_ctxs ) {
             m_workers.emplace_back( [this, ctx] () { workerMain( ctx ); } );
@@ -286,7 +304,7 @@ public:
             if ( worker.joinable() ) worker.join();
         }
         m_prefetching.clear();
-        for ( auto* const ctx : m_ctxs ) mi355x_bz2_destroy( ctx );
+        for ( auto it = m_ctxs.rbegin(); it != m_ctxs.rend(); ++it ) mi355x_bz2_destroy( *it );   /* owner of the input last */
     }
 
     /** BZ2BlockFetcher::readBlockHeader, BZ2BlockFetcher.hpp:64-82, for the EOS / next-stream probe on the caller
@@ -419,6 +437,13 @@ private:
     {
         std::vector<uint64_t> offsets;
         std::vector<std::promise<BlockDataPtr> > promises;
+        std::shared_ptr<std::atomic<bool> > done;   /* set after the last promise: the futures of a batch become ready together */
+    };
+
+    struct BatchInFlight
+    {
+        std::shared_ptr<std::atomic<bool> > done;
+        std::vector<uint64_t> offsets;
     };
 
     void
@@ -437,13 +462,20 @@ private:
                || m_cache.test( blockOffset ) || m_prefetchCache.test( blockOffset );
     }
 
-    /** processReadyPrefetches, BlockFetcher.hpp:414-438 */
+    /** processReadyPrefetches, BlockFetcher.hpp:414-438.  The reference polls every future; here all futures of a batch
+     * become ready together, so one flag per batch is polled (a get() with 5 000 blocks in flight must not cost 5 000
+     * future look-ups: that alone capped the reader at 5 GB/s). */
     void
     processReadyPrefetches()
     {
-        using namespace std::chrono_literals;
-        for ( auto it = m_prefetching.begin(); it != m_prefetching.end(); ) {
-            if ( it->second.wait_for( 0s ) == std::future_status::ready ) {
+        for ( auto batch = m_batchesInFlight.begin(); batch != m_batchesInFlight.end(); ) {
+            if ( !batch->done->load( std::memory_order_acquire ) ) {
+                ++batch;
+                continue;
+            }
+            for ( const auto offset : batch->offsets ) {
+                const auto it = m_prefetching.find( offset );
+                if ( it == m_prefetching.end() ) continue;     /* fetched on demand meanwhile */
                 const auto result = it->second.get();
                 if ( result && ( result->status == MI355X_BZ2_OK ) ) {
                     m_prefetchCache.insert( it->first, result );
@@ -452,10 +484,9 @@ private:
                     m_failedPrefetchCache.insert( it->first, true );
                     ++m_stats.failed_prefetches;
                 }
-                it = m_prefetching.erase( it );
-            } else {
-                ++it;
+                m_prefetching.erase( it );
             }
+            batch = m_batchesInFlight.erase( batch );
         }
     }
 
@@ -501,6 +532,8 @@ private:
         auto request = std::make_unique<Request>();
         request->offsets = offsets;
         request->promises.resize( offsets.size() );
+        request->done = std::make_shared<std::atomic<bool> >( false );
+        m_batchesInFlight.push_back( BatchInFlight{ request->done, offsets } );
         std::vector<std::shared_future<BlockDataPtr> > futures;
         futures.reserve( offsets.size() );
         for ( auto& promise : request->promises ) {
@@ -551,6 +584,7 @@ private:
                 for ( auto& promise : request->promises ) {
                     promise.set_value( nullptr );
                 }
+                request->done->store( true, std::memory_order_release );
                 continue;
             }
             for ( uint32_t i = 0; i < n; ++i ) {
@@ -570,6 +604,7 @@ private:
                 }
                 request->promises[i].set_value( std::move( block ) );
             }
+            request->done->store( true, std::memory_order_release );
             const std::scoped_lock lock( m_queueMutex );
             ++m_batches;
             m_blocksDecoded += n;
@@ -587,6 +622,7 @@ private:
     LruCache<size_t, BlockDataPtr> m_prefetchCache;
     LruCache<size_t, bool> m_failedPrefetchCache;
     std::map<size_t, std::shared_future<BlockDataPtr> > m_prefetching;
+    std::list<BatchInFlight> m_batchesInFlight;
 
     std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };
@@ -926,10 +962,11 @@ private:
         if ( m_blockFetcher ) {
             return *m_blockFetcher;
         }
+        (void)blockFinder();
+        m_blockFetcher = std::make_unique<GpuBlockFetcher>( m_source, m_blockFinder, m_parallelization, m_device );
         if ( !blockFinder().finalized() ) {
             blockFinder().startThreads();
         }
-        m_blockFetcher = std::make_unique<GpuBlockFetcher>( m_source, m_blockFinder, m_parallelization, m_device );
         return *m_blockFetcher;
     }
 

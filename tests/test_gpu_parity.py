@@ -167,6 +167,33 @@ def test_begin_end_halves_and_two_contexts(native, oracle):
         d.close()
 
 
+def test_two_contexts_over_one_resident_input(native, oracle):
+    """mi355x_bz2_share_input: the second context decodes from the bytes the first one uploaded (what the reader does
+    for its two contexts); halves of the block list on each, interleaved."""
+    raw = datagen.text_like(2_000_000, 53) + datagen.random_bytes(500_000, 54)
+    enc = datagen.compress(raw, 9)
+    offs = native.find_magic(enc)
+    a = native.Decoder()
+    a.set_input(enc)
+    b = native.Decoder()
+    with pytest.raises(native.Bz2Error):
+        b.share_input(native.Decoder())          # nothing resident there
+    b.share_input(a)
+    want, total = a.decode_batch(offs)
+    assert a.copy_output(0, total) == raw
+    got, total_b = b.decode_batch(offs)
+    assert (got, total_b) == (want, total) and b.copy_output(0, total_b) == raw
+    half = len(offs) // 2
+    arr_a, arr_b = a.make_arrays(offs[:half]), b.make_arrays(offs[half:])
+    a.begin_batch(arr_a[0], half)
+    b.begin_batch(arr_b[0], len(offs) - half)
+    ta, tb = a.end_batch(arr_a[1]), b.end_batch(arr_b[1])
+    assert a.copy_output(0, ta) + b.copy_output(0, tb) == raw
+    assert b.find_magic() == offs                 # the scan sees the shared bytes too
+    b.close()
+    a.close()
+
+
 @pytest.mark.parametrize("symbols", [1, 2, 15, 16, 17, 127, 128, 129, 255, 256])
 def test_alphabet_sizes_around_the_list_variants(native, oracle, dec, symbols):
     """k_mtf runs in two instances (128-entry and 256-entry lists) chosen by the block's symbol count; 16-entry groups
