@@ -22,6 +22,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <iostream>
@@ -178,7 +179,10 @@ public:
             }
         }
         if ( buffer.data == nullptr ) {
-            buffer.capacity = std::max<size_t>( size, 1 );
+            /* batches of one sequential read differ a little in size: leave headroom so that a recycled buffer fits
+             * the next batch instead of pinning fresh memory (which costs more than the copy) */
+            const size_t grain = size < ( size_t( 8 ) << 20 ) ? ( size_t( 1 ) << 20 ) : ( size_t( 16 ) << 20 );
+            buffer.capacity = ( std::max<size_t>( size + size / 8, 1 ) + grain - 1 ) / grain * grain;
             if ( hipHostMalloc( reinterpret_cast<void**>( &buffer.data ), buffer.capacity, hipHostMallocDefault ) != hipSuccess ) {
                 return nullptr;
             }
@@ -241,20 +245,30 @@ public:
         m_blockFinder( std::move( finder ) ),
         m_parallelization( std::max<size_t>( 1, parallelization ) ),
         m_cache( std::max<size_t>( 16, m_parallelization ) ),              /* BlockFetcher.hpp:180 */
-        m_prefetchCache( 2 * m_parallelization ),                          /* BlockFetcher.hpp:181 */
-        m_failedPrefetchCache( 2 * m_parallelization )                     /* BlockFetcher.hpp:182 */
+        /* BlockFetcher.hpp:181-182 use 2 P.  The prefetch window (= this capacity) bounds decoded-but-unread blocks plus
+         * blocks in flight; with 2 P a second full batch could only start once the reader had consumed all of the first,
+         * so launches went out with P / 2 blocks each (80 ms latency floor per launch: 5 GB/s at P = 512).  (contexts + 2) P
+         * lets every context have a full batch in flight while another one is being read. */
+        m_prefetchCache( ( contextCount( m_parallelization ) + 2 ) * m_parallelization ),
+        m_failedPrefetchCache( ( contextCount( m_parallelization ) + 2 ) * m_parallelization )
     {
         /* BZ2BlockFetcher ctor reads the stream header once: BZ2BlockFetcher.hpp:56 */
         if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), 0 ) == 0 ) {
             fail( MI355X_BZ2_ERR_STREAM_HEADER );
         }
-        /* Two decoder contexts, each with its own submission thread, once batches are large enough to be worth it:
-         * while one batch is copied to the host (and consumed), the next one is already being decoded. */
-        const size_t nContexts = m_parallelization >= 64 ? 2 : 1;
+        /* Several decoder contexts, each with its own submission thread, once batches are large enough to be worth it:
+         * while one batch is copied to the host (and consumed), the next ones are already being decoded.  A batch has a
+         * latency floor of ~80 ms (one wave per block in the Huffman stage), so smaller batches want more of them in
+         * flight: three contexts up to P = 640 (20 GB of scratch at the default P = 512), two above. */
+        const size_t nContexts = contextCount( m_parallelization );
+        const auto tCtor = std::chrono::steady_clock::now();
         for ( size_t i = 0; i < nContexts; ++i ) {
             mi355x_bz2_config config{};
             config.device = device;
-            config.max_batch_blocks = (uint32_t)std::min<size_t>( m_parallelization, 4096 );
+            /* scratch (13 MB per block, ~35 ms per GB to allocate) grows with the batches that are really launched: a
+             * reader that seeks and reads a little never pays for P blocks, a sequential one pays once per context, on
+             * that context's own thread */
+            config.max_batch_blocks = (uint32_t)std::min<size_t>( m_parallelization, 64 );
             mi355x_bz2_ctx* ctx = nullptr;
             int rc = mi355x_bz2_create( &config, &ctx );
             std::string detail;
@@ -278,6 +292,7 @@ public:
          * host finder threads (ParallelBitStringFinder's job, ~1.3 GB/s of compressed data on eight cores) would
          * otherwise pace the whole reader.  Same offsets, delivered at once; if the scan cannot be used (more matches
          * than its result buffer holds) the host threads take over as before. */
+        const auto tInput = std::chrono::steady_clock::now();
         if ( !m_blockFinder->finalized() ) {
             /* the scan keeps up to 2^20 matches (>= 100 GB of level-9 data) and reports MI355X_BZ2_ERR_OUTPUT_CAPACITY beyond */
             std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
@@ -287,6 +302,13 @@ public:
                 offsets.resize( found );
                 m_blockFinder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
             }
+        }
+        if ( m_trace ) {
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf( stderr, "[reader] %zu contexts + %.0f MB resident: %.1f ms, magic scan: %.1f ms (%zu blocks)\n",
+                          m_ctxs.size(), m_source->size() / 1e6,
+                          std::chrono::duration<double, std::milli>( tInput - tCtor ).count(),
+                          std::chrono::duration<double, std::milli>( now - tInput ).count(), m_blockFinder->size() );
         }
         for ( auto* const ctx : m_ctxs ) {
             m_workers.emplace_back( [this, ctx] () { workerMain( ctx ); } );
@@ -305,6 +327,15 @@ public:
         }
         m_prefetching.clear();
         for ( auto it = m_ctxs.rbegin(); it != m_ctxs.rend(); ++it ) mi355x_bz2_destroy( *it );   /* owner of the input last */
+    }
+
+    [[nodiscard]] static size_t
+    contextCount( size_t parallelization )
+    {
+        if ( const char* const forced = std::getenv( "MI355X_BZ2_READER_CONTEXTS" ) ) {
+            return std::min<size_t>( 4, std::max<size_t>( 1, std::strtoul( forced, nullptr, 10 ) ) );
+        }
+        return parallelization >= 64 ? ( parallelization <= 640 ? 3 : 2 ) : 1;
     }
 
     /** BZ2BlockFetcher::readBlockHeader, BZ2BlockFetcher.hpp:64-82, for the EOS / next-stream probe on the caller
@@ -499,6 +530,13 @@ private:
         const auto inFlight = m_prefetching.size() + ( onDemand ? 1 : 0 );
         const size_t limit = m_parallelization * m_ctxs.size();
         if ( inFlight >= limit ) return;
+        /* The candidate search below looks at up to 2 P indexes.  While a launch is held back for want of candidates
+         * (see the batching rule at the end) a sequential reader gains about one candidate per get(): searching again
+         * on every call would cost O(P^2) per batch (1 s per 2 560 blocks), so the search is skipped for a while. */
+        if ( !onDemand && ( m_skipCollect > 0 ) && !m_prefetching.empty() ) {
+            --m_skipCollect;
+            return;
+        }
         const size_t room = std::min( limit - inFlight, m_parallelization );
 
         const auto indexes = m_fetchingStrategy.prefetch( m_prefetchCache.capacity() );
@@ -517,12 +555,18 @@ private:
             if ( m_prefetching.size() + candidates.size() + 1 > m_prefetchCache.capacity() ) break;
             candidates.push_back( *offset );
         }
-        if ( candidates.empty() ) return;
+        if ( candidates.empty() ) {
+            m_skipCollect = std::max<size_t>( 1, m_parallelization / 8 );
+            return;
+        }
         /* GPU batching rule: piggy-back on an on-demand launch, otherwise wait until at least P/2 blocks can go in one
          * launch (or nothing is in flight at all). */
         const size_t batchMin = std::max<size_t>( 1, m_parallelization / 2 );
         if ( onDemand || ( candidates.size() >= batchMin ) || m_prefetching.empty() ) {
             batch.insert( batch.end(), candidates.begin(), candidates.end() );
+            m_skipCollect = 0;
+        } else {
+            m_skipCollect = std::min( batchMin - candidates.size(), std::max<size_t>( 1, m_parallelization / 8 ) );
         }
     }
 
@@ -567,14 +611,23 @@ private:
             std::vector<mi355x_bz2_block_result> results( n );
             uint64_t total = 0;
             int rc = mi355x_bz2_decode_batch( ctx, request->offsets.data(), n, results.data(), &total );
+            const auto t1 = std::chrono::steady_clock::now();
+            auto t2 = t1;
             std::shared_ptr<const uint8_t> buffer;
             if ( rc == MI355X_BZ2_OK ) {
                 buffer = m_hostBuffers->get( total, m_hostBuffers );
+                t2 = std::chrono::steady_clock::now();
                 if ( !buffer ) {
                     rc = MI355X_BZ2_ERR_DEVICE;
                 } else if ( total > 0 ) {
                     rc = mi355x_bz2_copy_output( ctx, 0, total, const_cast<uint8_t*>( buffer.get() ) );
                 }
+            }
+            if ( m_trace ) {
+                const auto ms = [] ( auto a, auto b ) { return std::chrono::duration<double, std::milli>( b - a ).count(); };
+                const auto t3 = std::chrono::steady_clock::now();
+                std::fprintf( stderr, "[reader] batch of %u blocks on ctx %p: decode %.1f ms, host buffer %.1f ms, copy of "
+                              "%.0f MB %.1f ms\n", n, (void*)ctx, ms( t0, t1 ), ms( t1, t2 ), total / 1e6, ms( t2, t3 ) );
             }
             if ( rc != MI355X_BZ2_OK ) {
                 {
@@ -623,6 +676,7 @@ private:
     LruCache<size_t, bool> m_failedPrefetchCache;
     std::map<size_t, std::shared_future<BlockDataPtr> > m_prefetching;
     std::list<BatchInFlight> m_batchesInFlight;
+    size_t m_skipCollect{ 0 };
 
     std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };
@@ -631,6 +685,7 @@ private:
     std::condition_variable m_queueChanged;
     std::queue<std::unique_ptr<Request> > m_queue;
     bool m_stop{ false };
+    const bool m_trace{ std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr };
     std::string m_workerError;
     uint64_t m_batches{ 0 };
     uint64_t m_blocksDecoded{ 0 };
