@@ -238,3 +238,38 @@ def test_text_index_roundtrip(native, oracle, three_block_file, tmp_path):
         assert g.statistics()["blocks_decoded"] <= 3
     with pytest.raises(ValueError):
         native.read_block_offsets(io.StringIO("12;5\n"))
+
+
+@pytest.mark.parametrize("parallelization", [64, 100, 700])
+def test_many_batches_in_flight(native, oracle, parallelization):
+    """Several contexts and a prefetch window of (contexts + 2) P: a file of ~285 small blocks read sequentially goes
+    through many overlapping batches (three contexts at P = 64 and 100, two at 700 with the file shorter than the
+    window); block magics come from the GPU scan.  Every byte, the block map and the stream CRCs must come out as with
+    one block at a time."""
+    parts = [datagen.text_like(9_000_000, 81), datagen.random_bytes(3_000_000, 82), datagen.runs(4_000_000, 83),
+             datagen.random_text_file(16_000_000, 84)]
+    raw = b"".join(parts)
+    enc = datagen.multistream(parts, 1)
+    want_offsets = oracle.find_magic(enc, oracle.MAGIC_BLOCK)
+    assert len(want_offsets) > 250
+    with native.open(io.BytesIO(enc), parallelization) as f:
+        f.set_verify_stream_crc(True)
+        got = bytearray()
+        while True:
+            piece = f.read(3_000_001)
+            if not piece:
+                break
+            got += piece
+        assert bytes(got) == raw
+        assert f.streams_verified() == len(parts)
+        offsets = f.block_offsets()
+        st = f.statistics()
+        assert st["batches"] >= (2 if parallelization < 200 else 1) and st["failed_prefetches"] == 0
+        # data blocks of the map are exactly the magics found (+ EOS entries and the end), sizes add up
+        assert [o for o in sorted(offsets) if o in set(want_offsets)] == want_offsets
+        assert max(offsets.values()) == len(raw)
+        # backwards seek into an evicted region, then on to the end
+        f.seek(len(raw) // 3)
+        assert f.read(100_000) == raw[len(raw) // 3:len(raw) // 3 + 100_000]
+        f.seek(-5, io.SEEK_END)
+        assert f.read() == raw[-5:]

@@ -22,6 +22,7 @@ def main():
         fd = os.open("/dev/null", os.O_WRONLY)
         t0 = time.perf_counter()
         f = m.IndexedBzip2FileRaw(big, P)
+        f.bz2reader.set_verify_stream_crc(True)
         t1 = time.perf_counter()
         n = f.bz2reader.read_to_fd(fd, 1 << 20)
         t2 = time.perf_counter()
@@ -34,6 +35,7 @@ def main():
             marks.append(time.perf_counter())
         dt = time.perf_counter() - t0
         st = f.bz2reader.statistics()
+        assert n == copies * meta["decoded_bytes"] and f.bz2reader.streams_verified() == copies, (n, f.bz2reader.streams_verified())
         f.close()
         os.close(fd)
         per_gib = [round((b - a) * 1e3) for a, b in zip([t2] + marks[:-1], marks)]
