@@ -259,7 +259,8 @@ public:
         /* Several decoder contexts, each with its own submission thread, once batches are large enough to be worth it:
          * while one batch is copied to the host (and consumed), the next ones are already being decoded.  A batch has a
          * latency floor of ~80 ms (one wave per block in the Huffman stage), so smaller batches want more of them in
-         * flight: three contexts up to P = 640 (20 GB of scratch at the default P = 512), two above. */
+         * flight: three contexts up to P = 640 (20 GB of scratch at the default P = 512), two above.  Small P keeps two so that
+         * an on-demand block does not have to wait for a prefetch launch (see get()); P = 1 is the serial reader. */
         const size_t nContexts = contextCount( m_parallelization );
         const auto tCtor = std::chrono::steady_clock::now();
         for ( size_t i = 0; i < nContexts; ++i ) {
@@ -335,7 +336,7 @@ public:
         if ( const char* const forced = std::getenv( "MI355X_BZ2_READER_CONTEXTS" ) ) {
             return std::min<size_t>( 4, std::max<size_t>( 1, std::strtoul( forced, nullptr, 10 ) ) );
         }
-        return parallelization >= 64 ? ( parallelization <= 640 ? 3 : 2 ) : 1;
+        return parallelization >= 64 ? ( parallelization <= 640 ? 3 : 2 ) : ( parallelization >= 2 ? 2 : 1 );
     }
 
     /** BZ2BlockFetcher::readBlockHeader, BZ2BlockFetcher.hpp:64-82, for the EOS / next-stream probe on the caller
@@ -418,8 +419,19 @@ public:
         m_fetchingStrategy.fetch( validDataBlockIndex );
         collectPrefetches( batch, onDemand, blockOffset );
 
-        if ( !batch.empty() ) {
-            auto futures = submitBatch( batch );
+        if ( onDemand && ( batch.size() > 1 ) && ( m_ctxs.size() >= 2 ) ) {
+            /* A batch returns when its slowest block is through (an incompressible block takes 68 ms, a text block
+             * 24 ms): the block the caller is waiting for goes alone, ahead of everything queued, and its prefetch
+             * companions as a second launch on another context. */
+            queued = submitBatch( { batch[0] }, /* urgent */ true )[0];
+            const std::vector<uint64_t> companions( batch.begin() + 1, batch.end() );
+            const auto futures = submitBatch( companions );
+            for ( size_t i = 0; i < companions.size(); ++i ) {
+                m_prefetching.emplace( companions[i], futures[i] );
+                ++m_stats.prefetches_submitted;
+            }
+        } else if ( !batch.empty() ) {
+            auto futures = submitBatch( batch, onDemand );
             size_t first = 0;
             if ( onDemand ) {
                 queued = futures[0];
@@ -571,7 +583,7 @@ private:
     }
 
     [[nodiscard]] std::vector<std::shared_future<BlockDataPtr> >
-    submitBatch( const std::vector<uint64_t>& offsets )
+    submitBatch( const std::vector<uint64_t>& offsets, bool urgent = false )
     {
         auto request = std::make_unique<Request>();
         request->offsets = offsets;
@@ -585,7 +597,11 @@ private:
         }
         {
             const std::scoped_lock lock( m_queueMutex );
-            m_queue.push( std::move( request ) );
+            if ( urgent ) {
+                m_queue.push_front( std::move( request ) );   /* someone is waiting for it */
+            } else {
+                m_queue.push_back( std::move( request ) );
+            }
             m_queueChanged.notify_all();
         }
         return futures;
@@ -604,7 +620,7 @@ private:
                     return;   /* m_stop */
                 }
                 request = std::move( m_queue.front() );
-                m_queue.pop();
+                m_queue.pop_front();
             }
             const auto t0 = std::chrono::steady_clock::now();
             const auto n = (uint32_t)request->offsets.size();
@@ -683,7 +699,7 @@ private:
     std::vector<std::thread> m_workers;
     mutable std::mutex m_queueMutex;
     std::condition_variable m_queueChanged;
-    std::queue<std::unique_ptr<Request> > m_queue;
+    std::deque<std::unique_ptr<Request> > m_queue;
     bool m_stop{ false };
     const bool m_trace{ std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr };
     std::string m_workerError;

@@ -38,16 +38,16 @@ def timed_steps(dec, offs_c, n, res_c, steps):
     return (time.perf_counter() - t0) / steps, total
 
 
-def config2_and_5(out):
+def config2_and_5(out, only5=False):
     path, enc, meta = bench.build_workload(2 * 1024**3, 214_748_364, "/tmp/indexed_bzip2_amd_bench", 0, 1, lambda: None)
     offsets = meta["offsets"]
     d_in = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
-    dec = m.Decoder(device=0, max_batch_blocks=len(offsets))
+    dec = m.Decoder(device=0, max_batch_blocks=64 if only5 else len(offsets))
     dec.set_input_device(d_in.data_ptr(), len(enc), keepalive=d_in)
     sweep = []
+    sub = offsets[:640] if not only5 else []
     # the first quarter of the file (640 blocks ~ 512 MiB decoded) in batches of B blocks
-    sub = offsets[:640]
-    for B in (32, 64, 128, 256, 640):
+    for B in (32, 64, 128, 256, 640) if not only5 else ():
         arrays = [dec.make_arrays(sub[i:i + B]) for i in range(0, len(sub), B)]
         for a, r in arrays:
             dec.decode_batch_into(a, len(a), r)
@@ -60,7 +60,8 @@ def config2_and_5(out):
         dt = time.perf_counter() - t0
         sweep.append({"blocks_per_batch": B, "MBps": round(total / dt / 1e6, 1), "ms_per_batch": round(dt / len(arrays) * 1e3, 2)})
         log("config2", sweep[-1])
-    out["config2_batch_sweep"] = {"workload": "first 640 blocks (537 MB decoded) of the config-4 file, input resident in HBM, "
+    if not only5:
+      out["config2_batch_sweep"] = {"workload": "first 640 blocks (537 MB decoded) of the config-4 file, input resident in HBM, "
                                               "output left in HBM", "results": sweep}
     dec.close()
     del d_in
@@ -73,7 +74,7 @@ def config2_and_5(out):
     size = meta["decoded_bytes"]
     rng = np.random.default_rng(0x5EEC)
     positions = rng.integers(0, size - 65536, 1000)
-    for P in (1, 4):
+    for P in (1, 4, 0):
         with m.open(path, parallelization=P) as g:
             g.set_block_offsets(index)
             lat = []
@@ -112,7 +113,7 @@ def config3(out):
     enc = open(cache, "rb").read()
     offsets = json.load(open(cache + ".json"))["offsets"]
     d_in = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
-    dec = m.Decoder(device=0, max_batch_blocks=len(offsets))
+    dec = m.Decoder(device=0, max_batch_blocks=64 if only5 else len(offsets))
     dec.set_input_device(d_in.data_ptr(), len(enc), keepalive=d_in)
     res, total = dec.decode_batch(offsets)
     assert all(r["status"] == 0 for r in res) and total == 2_147_483_640
@@ -131,8 +132,10 @@ def config3(out):
 
 def main():
     out = {}
-    config3(out)
-    config2_and_5(out)
+    only5 = len(sys.argv) > 1 and sys.argv[1] == "5"
+    if not only5:
+        config3(out)
+    config2_and_5(out, only5)
     print(json.dumps(out, indent=1))
 
 
