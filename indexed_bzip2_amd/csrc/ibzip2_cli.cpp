@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -432,6 +433,7 @@ main( int argc, char** argv )
             }
         }
 
+        const auto tOpen = std::chrono::steady_clock::now();
         mi355x_bz2_reader* reader = nullptr;
         int rc = mi355x_bz2_reader_open_memory( in.data, in.size, o.decoderParallelism, o.device, &reader );
         if ( rc != MI355X_BZ2_OK ) {
@@ -450,6 +452,7 @@ main( int argc, char** argv )
             return 1;
         };
 
+        const auto tRead = std::chrono::steady_clock::now();
         uint64_t written = 0;
         if ( o.bufferSize > 0 ) {
             std::vector<char> buffer( o.bufferSize );
@@ -476,6 +479,7 @@ main( int argc, char** argv )
             if ( rc != MI355X_BZ2_OK ) return fail( rc );
         }
         if ( outFd >= 0 && !writingToStdout ) ::close( outFd );
+        const auto tDone = std::chrono::steady_clock::now();
 
         std::ostream& out = writingToStdout ? std::cerr : std::cout;
 
@@ -513,6 +517,11 @@ main( int argc, char** argv )
             }
         }
         mi355x_bz2_reader_close( reader );
+        if ( o.verbose > 1 ) {
+            const auto seconds = [] ( auto a, auto b ) { return std::chrono::duration<double>( b - a ).count(); };
+            std::cerr << "[timing] open " << seconds( tOpen, tRead ) << " s, decode " << seconds( tRead, tDone )
+                      << " s, close " << seconds( tDone, std::chrono::steady_clock::now() ) << " s\n";
+        }
 
         if ( o.listOffsets ) {
             if ( !o.listOffsetsPath.empty() ) {
