@@ -227,6 +227,7 @@ struct BlockData : public BlockHeaderData
     std::shared_ptr<const uint8_t> buffer;   /* page-locked host copy of the whole batch output */
     size_t dataOffset{ 0 };
     size_t dataSize{ 0 };
+    size_t batchBytes{ 0 };                  /* decoded bytes that share `buffer` */
     uint32_t calculatedCRC{ 0xFFFFFFFFu };
     int status{ MI355X_BZ2_OK };
 
@@ -494,6 +495,17 @@ private:
     {
         if ( m_fetchingStrategy.isSequential() ) {
             m_cache.clear();   /* BlockFetcher.hpp:343-346 */
+        } else if ( blockData && blockData->buffer
+                    && ( blockData->batchBytes > 8 * std::max<size_t>( blockData->dataSize, size_t( 1 ) << 20 ) ) ) {
+            /* A block shares the page-locked buffer of its whole batch.  This cache survives random access for a long
+             * time: one kept block must not hold hundreds of MB of a batch whose other blocks are long gone. */
+            auto own = std::make_shared<BlockData>( *blockData );
+            std::shared_ptr<uint8_t> bytes( new uint8_t[std::max<size_t>( own->dataSize, 1 )], std::default_delete<uint8_t[]>() );
+            std::memcpy( bytes.get(), blockData->data(), own->dataSize );
+            own->buffer = std::move( bytes );
+            own->dataOffset = 0;
+            own->batchBytes = own->dataSize;
+            blockData = std::move( own );
         }
         m_cache.insert( blockOffset, std::move( blockData ) );
     }
@@ -670,6 +682,7 @@ private:
                     block->buffer = buffer;
                     block->dataOffset = r.data_offset;
                     block->dataSize = r.decoded_size;
+                    block->batchBytes = total;
                 }
                 request->promises[i].set_value( std::move( block ) );
             }
