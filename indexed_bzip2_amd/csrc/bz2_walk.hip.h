@@ -5,10 +5,15 @@
  * (FETCH_SIZE 127 GB per pass for 9 GB of tables): ~60 blocks' tables (230 MB) were in flight at once, so nothing
  * stayed in an XCD's 4 MiB L2.  Here every block is assigned to ONE XCD queue (block i -> queue i mod 8), each
  * workgroup reads its XCC id (s_getreg HW_REG_XCC_ID) and pulls chunks of consecutive segments from its own XCD's
- * queue, and the grid is kept small (48 workgroups per XCD), so an XCD works on one or two 3.6 MB tables at a time and
- * the gathers hit its L2.  Lanes refill from the chunk through an LDS counter, so a short segment does not idle its
- * lane.  A workgroup whose queue is exhausted helps the other queues; nobody ever waits on another workgroup, every
- * loop is bounded by atomic counters that only grow, so the grid always drains.  Placement affects speed only.
+ * queue, so an XCD works on two or three 3.6 MB tables at a time (WALK_WGS_PER_XCD = 256 workgroups of 256 lanes = all
+ * wave slots: measured best; 48 workgroups kept one table per L2 but hid too little latency).  The gathers still miss
+ * L2 mostly (35 B of fabric traffic per step, PMC) but are served by the 256 MB MALL rather than HBM.  Lanes refill
+ * from the chunk through an LDS counter, so a short segment does not idle its lane.  A workgroup whose queue is
+ * exhausted helps the other queues; nobody ever waits on another workgroup, every loop is bounded by atomic counters
+ * that only grow, so the grid always drains.  Placement affects speed only.
+ *
+ * There is ONE gather pass: the walk keeps the first STASH_BYTES bytes of every segment (k_emit puts them in output
+ * order after k_link2 has ordered the segments), only longer segments are walked again from where the stash ends.
  *
  * Reference: the N-step dependent walk of BurrowsWheelerTransformData::decodeBlock, bzip2.hpp:872-879.
  */
