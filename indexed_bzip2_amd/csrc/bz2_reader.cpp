@@ -654,8 +654,9 @@ private:
             if ( m_trace ) {
                 const auto ms = [] ( auto a, auto b ) { return std::chrono::duration<double, std::milli>( b - a ).count(); };
                 const auto t3 = std::chrono::steady_clock::now();
-                std::fprintf( stderr, "[reader] batch of %u blocks on ctx %p: decode %.1f ms, host buffer %.1f ms, copy of "
-                              "%.0f MB %.1f ms\n", n, (void*)ctx, ms( t0, t1 ), ms( t1, t2 ), total / 1e6, ms( t2, t3 ) );
+                std::fprintf( stderr, "[reader] t=%.1f ms: batch of %u blocks on ctx %p: decode %.1f ms, host buffer %.1f ms, "
+                              "copy of %.0f MB %.1f ms\n", ms( m_created, t0 ), n, (void*)ctx, ms( t0, t1 ), ms( t1, t2 ),
+                              total / 1e6, ms( t2, t3 ) );
             }
             if ( rc != MI355X_BZ2_OK ) {
                 {
@@ -715,6 +716,7 @@ private:
     std::deque<std::unique_ptr<Request> > m_queue;
     bool m_stop{ false };
     const bool m_trace{ std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr };
+    const std::chrono::steady_clock::time_point m_created{ std::chrono::steady_clock::now() };
     std::string m_workerError;
     uint64_t m_batches{ 0 };
     uint64_t m_blocksDecoded{ 0 };
