@@ -616,8 +616,10 @@ k_rle( BlockMeta*                   meta,
  * zero-init CRC), trailing pad is undone with x^(-8*pad).  Init/final XOR are applied at the end.
  * ============================================================================================================= */
 constexpr uint32_t CRC_THREADS = 256;
-constexpr uint32_t CRC_CHUNK = 64;
-constexpr uint32_t CRC_TILE = CRC_THREADS * CRC_CHUNK;   /* 16 KiB = 64 * 2^8 bytes */
+constexpr uint32_t CRC_CHUNK_LOG2 = 8;
+constexpr uint32_t CRC_CHUNK = 1u << CRC_CHUNK_LOG2;     /* bytes per lane and tile: the combine tree (6 + 5 GF(2) multiplications
+                                                             per tile) is the expensive part, so few, large tiles */
+constexpr uint32_t CRC_TILE = CRC_THREADS * CRC_CHUNK;   /* 64 KiB */
 constexpr uint32_t CRC_POLY = 0x04C11DB7u;
 
 __device__ __forceinline__ uint32_t
@@ -675,8 +677,8 @@ k_crc( BlockMeta*                  meta,
         if ( c0 + CRC_CHUNK > a0 && c0 < a1 ) {
             if ( aligned && c0 >= a0 && c0 + CRC_CHUNK <= a1 ) {
                 const uint4* src = reinterpret_cast<const uint4*>( out + c0 );
-#pragma unroll
-                for ( int v = 0; v < 4; ++v ) {
+#pragma unroll 4
+                for ( uint32_t v = 0; v < CRC_CHUNK / 16; ++v ) {
                     const uint4 d = src[v];
                     const uint32_t ws[4] = { d.x, d.y, d.z, d.w };
 #pragma unroll
@@ -697,18 +699,18 @@ k_crc( BlockMeta*                  meta,
             }
         }
         /* wave tree: after step d lane i (i % 2d == 0) holds the CRC of chunks [i, i+2d) */
-        for ( int d = 1, k = 6; d < 64; d <<= 1, ++k ) {
+        for ( int d = 1, k = CRC_CHUNK_LOG2; d < 64; d <<= 1, ++k ) {
             const uint32_t right = __shfl_down( crc, d );
-            crc = gf_mul( crc, cc.pow8[k] ) ^ right;   /* pow8[k] = x^(8 * 64 * d) since 64*d = 2^k */
+            crc = gf_mul( crc, cc.pow8[k] ) ^ right;   /* pow8[k] = x^(8 * CRC_CHUNK * d) since CRC_CHUNK * d = 2^k */
         }
         if ( lane == 0 ) wcrc[wave] = crc;
         __syncthreads();
         if ( tid == 0 ) {
             uint32_t tileCrc = 0;
             for ( uint32_t w = 0; w < CRC_THREADS / 64; ++w ) {
-                tileCrc = gf_mul( tileCrc, cc.pow8[12] ) ^ wcrc[w];   /* 4096 bytes per wave */
+                tileCrc = gf_mul( tileCrc, cc.pow8[CRC_CHUNK_LOG2 + 6] ) ^ wcrc[w];   /* 64 chunks per wave */
             }
-            running = gf_mul( running, cc.pow8[14] ) ^ tileCrc;       /* 16384 bytes per tile */
+            running = gf_mul( running, cc.pow8[CRC_CHUNK_LOG2 + 8] ) ^ tileCrc;       /* CRC_TILE bytes per tile */
         }
         __syncthreads();
         tEnd = t + CRC_TILE;
