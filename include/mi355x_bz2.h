@@ -121,7 +121,11 @@ void mi355x_bz2_destroy( mi355x_bz2_ctx* ctx );
 const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
 
 /* Make the compressed file (or any byte range of it; bit offsets below are relative to `bytes[0]`) resident in HBM.
- * _host copies H2D into ctx-owned memory.  _device borrows a device pointer (must stay valid; size need not be padded).
+ * Both forms COPY into ctx-owned memory: the kernels read the stream as big-endian 32-bit words (byte-swapped once,
+ * while it is copied) with 16-byte loads and no bounds checks, so the copy is word-swapped and zero padded by >= 256
+ * bytes.  _host copies H2D (pageable or page-locked host memory), _device copies D2D from a device pointer that is
+ * only read during the call (4-byte aligned; size need not be padded).  The caller's buffer may be freed afterwards;
+ * the copy costs one extra `size` bytes of HBM.
  * Replaces the BitReader/SharedFileReader clone + pread of BZ2BlockFetcher.hpp:89-90. */
 int mi355x_bz2_set_input_host( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
 int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, uint64_t size );
@@ -129,6 +133,10 @@ int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, 
  * `ctx` decodes from the bytes `from` made resident.  Nothing is copied; `from` must outlive `ctx`'s use of them and
  * keep its input unchanged.  Both contexts must be on the same device. */
 int mi355x_bz2_share_input( mi355x_bz2_ctx* ctx, mi355x_bz2_ctx* from );
+
+/* A batch holds at most this many blocks (grid dimensions and 16-bit segment ids are sized for it; 65 535 level-9
+ * blocks are 59 GB of decoded data and 850 GB of scratch): larger requests fail with MI355X_BZ2_ERR_INVALID_ARGUMENT. */
+#define MI355X_BZ2_MAX_BATCH_BLOCKS 65535u
 
 /* Decode n_blocks independent blocks whose magic starts at block_bit_offsets[i] (from the finder or the index).
  * = n calls of BZ2BlockFetcher::decodeBlock (BZ2BlockFetcher.hpp:85-138).  An offset pointing at an EOS magic

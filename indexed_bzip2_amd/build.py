@@ -27,7 +27,8 @@ def needs_build():
     if not os.path.exists(OUT) or not os.path.exists(CLI_OUT):
         return True
     t = min(os.path.getmtime(OUT), os.path.getmtime(CLI_OUT))
-    deps = sources() + [CLI_SRC] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    deps = (sources() + [CLI_SRC] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+            + glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -20,6 +20,7 @@
 #include "../../include/mi355x_bz2.h"
 #include "bz2_kernels.hip.h"
 #include "bz2_stage1.hip.h"
+#include "bz2_hscan.hip.h"
 #include "bz2_walk.hip.h"
 
 using namespace bz2gpu;
@@ -53,6 +54,9 @@ struct mi355x_bz2_ctx
     uint16_t* dSym{ nullptr };
     uint8_t* dStb{ nullptr };
     HuffMeta* dHmeta{ nullptr };
+    ScanMeta* dSmeta{ nullptr };      /* k_hscan -> k_hsym */
+    HuffTables* dHtab{ nullptr };     /* decode tables per block */
+    uint32_t* dGpos{ nullptr };       /* [cap][GPOS_STRIDE]: bit position of every 50-symbol group */
     uint8_t* dL{ nullptr };
     uint32_t* dTab{ nullptr };
     uint8_t* dR{ nullptr };
@@ -79,6 +83,7 @@ struct mi355x_bz2_ctx
     hipEvent_t ev[MAX_GROUPS][2 * MI355X_BZ2_MAX_KERNELS]{};   /* [group][2 * kernel + {start, end}] */
     hipEvent_t evStep[3]{};                                     /* step start, inputs uploaded, step end */
     hipEvent_t evGroupDone[MAX_GROUPS]{};
+    uint32_t launched[MAX_GROUPS]{};                            /* bit k: kernel k was launched for the group in this batch */
     /* a batch between mi355x_bz2_decode_batch_begin and _end */
     uint32_t pendingBlocks{ 0 };
     int pendingGroups{ 0 }, pendingExpensive{ -1 };
@@ -148,6 +153,9 @@ freeScratch( mi355x_bz2_ctx* c )
     (void)hipFree( c->dSym ); c->dSym = nullptr;
     (void)hipFree( c->dStb ); c->dStb = nullptr;
     (void)hipFree( c->dHmeta ); c->dHmeta = nullptr;
+    (void)hipFree( c->dSmeta ); c->dSmeta = nullptr;
+    (void)hipFree( c->dHtab ); c->dHtab = nullptr;
+    (void)hipFree( c->dGpos ); c->dGpos = nullptr;
     (void)hipFree( c->dL ); c->dL = nullptr;
     (void)hipFree( c->dTab ); c->dTab = nullptr;
     (void)hipFree( c->dR ); c->dR = nullptr;
@@ -172,7 +180,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     freeScratch( c );
     /* about 13 MB of scratch per block: powers of two while that is cheap, multiples of 256 blocks beyond */
-    uint32_t cap = 64;
+    uint32_t cap = 8;
     while ( cap < nBlocks && cap < 512 ) cap *= 2;
     if ( cap < nBlocks ) cap = ( nBlocks + 255u ) & ~255u;
     HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
@@ -183,6 +191,9 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     HIP_TRY( c, hipMalloc( &c->dSym, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dStb, (size_t)cap * 256 ) );
     HIP_TRY( c, hipMalloc( &c->dHmeta, (size_t)cap * sizeof( HuffMeta ) ) );
+    HIP_TRY( c, hipMalloc( &c->dSmeta, (size_t)cap * sizeof( ScanMeta ) ) );
+    HIP_TRY( c, hipMalloc( &c->dHtab, (size_t)cap * sizeof( HuffTables ) ) );
+    HIP_TRY( c, hipMalloc( &c->dGpos, (size_t)cap * GPOS_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dL, (size_t)cap * L_STRIDE + 256 ) );
     HIP_TRY( c, hipMalloc( &c->dTab, (size_t)cap * TAB_STRIDE * sizeof( uint32_t ) ) );
     HIP_TRY( c, hipMalloc( &c->dR, (size_t)cap * L_STRIDE + 256 ) );
@@ -221,7 +232,7 @@ namespace
 {
 const char* const KERNEL_NAMES[] = {
     "k_huff", "k_mtf<272>", "k_bwt_build", "k_walk", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
-    "k_rle<true>", "k_crc", "k_walk_plan", "k_mtf<144>"
+    "k_rle<true>", "k_crc", "k_walk_plan", "k_mtf<144>", "k_hscan", "k_hsym"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
 static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
@@ -230,6 +241,7 @@ static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
 /* record an event pair around one launch so that every kernel gets its own device duration */
 #define TIMED_LAUNCH( ctx, group, queue, index, ... )                                      \
     do {                                                                                   \
+        ( ctx )->launched[group] |= 1u << ( index );                                       \
         HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[group][2 * ( index )], queue ) );        \
         hipLaunchKernelGGL( __VA_ARGS__ );                                                 \
         HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[group][2 * ( index ) + 1], queue ) );    \
@@ -307,7 +319,7 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
     c->flags = config != nullptr ? config->flags : 0;
     if ( hipSetDevice( device ) != hipSuccess
          || hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
-        delete c;
+        mi355x_bz2_destroy( c );   /* releases whatever exists so far */
         return MI355X_BZ2_ERR_DEVICE;
     }
     c->gstream[0] = c->stream;
@@ -318,28 +330,28 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
             /* gstream[MAX_GROUPS - 1] serves the expensive group: its k_huff is the longest chain of a batch */
             const int priority = g == MAX_GROUPS - 1 ? greatestPriority : ( leastPriority + greatestPriority ) / 2;
             if ( hipStreamCreateWithPriority( &c->gstream[g], hipStreamNonBlocking, priority ) != hipSuccess ) {
-                delete c;
+                mi355x_bz2_destroy( c );
                 return MI355X_BZ2_ERR_DEVICE;
             }
         }
     }
     for ( auto& e : c->evGroupDone ) {
         if ( hipEventCreate( &e ) != hipSuccess ) {
-            delete c;
+            mi355x_bz2_destroy( c );
             return MI355X_BZ2_ERR_DEVICE;
         }
     }
     for ( auto& group : c->ev ) {
         for ( auto& e : group ) {
             if ( hipEventCreate( &e ) != hipSuccess ) {
-                delete c;
+                mi355x_bz2_destroy( c );
                 return MI355X_BZ2_ERR_DEVICE;
             }
         }
     }
     for ( auto& e : c->evStep ) {
         if ( hipEventCreate( &e ) != hipSuccess ) {
-            delete c;
+            mi355x_bz2_destroy( c );
             return MI355X_BZ2_ERR_DEVICE;
         }
     }
@@ -490,7 +502,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     c->outSize = 0;
     c->lastBlocks = 0;
     if ( n == 0 ) return MI355X_BZ2_OK;
-    if ( n > 65535 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    if ( n > MI355X_BZ2_MAX_BATCH_BLOCKS ) {
+        c->lastError = "more than MI355X_BZ2_MAX_BATCH_BLOCKS blocks in one batch: split it";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
     if ( c->dIn == nullptr ) {
         c->lastError = "no input set";
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
@@ -578,6 +593,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         uint32_t* order = c->hOrder + groupFirst[g];
         for ( uint32_t k = 0; k < groupCount[g]; ++k ) order[k] = groupCount[g] - 1 - k;   /* group-relative slot */
     }
+    for ( auto& bits : c->launched ) bits = 0;
     HIP_TRY( c, hipEventRecord( c->evStep[0], c->stream ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOrder, c->hOrder, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
@@ -595,6 +611,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     /* tuning knobs: most k_huff workgroups of a cheap group / of the expensive group (0 = one per block) */
     const char* hc = std::getenv( "MI355X_BZ2_HUFF_GRID" );
     const uint32_t huffCap = hc != nullptr && std::atoi( hc ) > 0 ? (uint32_t)std::atoi( hc ) : 0xFFFFFFFFu;
+    /* Huffman stage: "scan" = k_hscan + k_hsym (group starts by pointer doubling, then one lane per group),
+     * "window" = k_huff (one serial chain per block) */
+    const char* hm = std::getenv( "MI355X_BZ2_HUFF" );
+    const bool useScan = !( hm != nullptr && std::strcmp( hm, "window" ) == 0 );
     const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
     const uint32_t huffCapExpensive = hce != nullptr && std::atoi( hce ) > 0 ? (uint32_t)std::atoi( hce ) : 0xFFFFFFFFu;
     for ( int launch = 0; launch < nGroups; ++launch ) {
@@ -622,10 +642,21 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         uint32_t* const walkPre = c->dWalkPre + (size_t)g * ( c->capacity + 16 );
         const dim3 walkGrid( WALK_QUEUES * wgsPerXcd );
 
-        const uint32_t huffGrid = std::min( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES, g == expensiveGroup ? huffCapExpensive : huffCap );
-        TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
-                      reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
-                      m, order );
+        if ( useScan ) {
+            ScanMeta* const smeta = c->dSmeta + first;
+            HuffTables* const htab = c->dHtab + first;
+            uint32_t* const gpos = c->dGpos + (size_t)first * GPOS_STRIDE;
+            TIMED_LAUNCH( c, g, q, 12, k_hscan, dim3( m ), dim3( 64 ), 0, q,
+                          reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, smeta,
+                          sel, stb, htab, gpos, m, order );
+            TIMED_LAUNCH( c, g, q, 13, k_hsym, dim3( ( MAX_SCAN_GROUPS + SYM_THREADS - 1 ) / SYM_THREADS, m ), dim3( SYM_THREADS ),
+                          0, q, reinterpret_cast<const uint32_t*>( c->dIn ), meta, hmeta, smeta, sel, htab, gpos, sym );
+        } else {
+            const uint32_t huffGrid = std::min( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES, g == expensiveGroup ? huffCapExpensive : huffCap );
+            TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
+                          reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
+                          m, order );
+        }
         TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
         TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
@@ -718,7 +749,7 @@ mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* c, mi355x_bz2_block_result* results
             std::fprintf( stderr, "[mi355x_bz2] group %d%s (%u blocks):", g, g == expensiveGroup ? " expensive" : "",
                           groupCount[g] );
             for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
-                if ( ( k == 8 || k == 9 ) && g >= 1 ) continue;
+                if ( !( c->launched[g] & ( 1u << k ) ) ) continue;
                 float t0 = 0, t1 = 0;
                 (void)hipEventElapsedTime( &t0, c->evStep[0], c->ev[g][2 * k] );
                 (void)hipEventElapsedTime( &t1, c->evStep[0], c->ev[g][2 * k + 1] );
@@ -763,7 +794,7 @@ mi355x_bz2_last_timings( const mi355x_bz2_ctx* c, mi355x_bz2_timings* t )
         float ms = 0;
         for ( uint32_t k = 0; k < N_KERNELS; ++k ) {
             for ( int g = 0; g < c->timingGroups; ++g ) {
-                if ( ( k == 8 || k == 9 ) && g >= 1 ) continue;   /* 8, 9: once for the whole batch */
+                if ( !( c->launched[g] & ( 1u << k ) ) ) continue;   /* e.g. 8, 9: once for the whole batch */
                 if ( hipEventElapsedTime( &ms, c->ev[g][2 * k], c->ev[g][2 * k + 1] ) == hipSuccess ) {
                     m->timings.ms_kernel[k] += ms;
                     m->timings.ms_kernel_sum += ms;

@@ -1,0 +1,713 @@
+/**
+ * bz2_hscan.hip.h -- Huffman stage in two kernels that break the one-serial-chain-per-block form of k_huff.
+ *
+ * The Huffman stream of a bzip2 block switches its code table every 50 symbols (Block::readBlockData,
+ * src/indexed_bzip2/bzip2.hpp:709-723), so a decoder that starts in the middle of a block knows neither the code
+ * alignment nor the table.  But the ONLY thing that is serial is the bit position at which every 50-symbol group starts:
+ * once those positions are known, all groups (18 000 per level-9 block) decode independently.
+ *
+ *   k_hscan  one wavefront per block.  Header, selectors, code lengths, canonical tables as in k_huff.  Then, group by
+ *            group: all 64 lanes look up the length of the code that WOULD start at each of S consecutive bit
+ *            positions (S = 64..1024, adapted to the table), which gives the successor array J1[i] = i + len(i); five
+ *            rounds of pointer doubling in LDS, J2k[i] = Jk[Jk[i]], give J2, J4, J8, J16, J32, and the group that starts
+ *            at bit x ends at J2[J16[J32[x]]] (32 + 16 + 2 = 50 symbols).  The dependent work per group is nine LDS
+ *            round trips instead of ~50 chain steps on the scalar unit, no symbol is produced, nothing is written but
+ *            one u32 per group.  End-of-block, "no code matches" and end-of-input positions are absorbing entries
+ *            (J[i] = i | FLAG), so the first group that runs into one of them is found exactly; consecutive groups with
+ *            the same table share one set of arrays.
+ *   k_hsym   one LANE per group: decodes its 50 symbols from the known start with the known table (per-lane bit reader,
+ *            {length, symbol} look-up table in LDS, canonical range search for long codes =
+ *            HuffmanCodingShortBitsCached::decode / decodeLong, src/huffman/HuffmanCodingShortBitsCached.hpp:98-150).
+ *            The lane of the block's last group applies the reference's end-of-input / invalid-code rules symbol by
+ *            symbol and writes the block's final record.
+ *
+ * k_mtf (bz2_stage1.hip.h) consumes the symbols exactly as it did from k_huff.
+ */
+#pragma once
+
+#include "bz2_stage1.hip.h"
+
+namespace bz2gpu
+{
+constexpr uint32_t SCAN_LUT_BITS = 10;
+constexpr uint32_t SCAN_LUT_SIZE = 1u << SCAN_LUT_BITS;
+constexpr uint32_t SCAN_MAX_SPAN = 1024;        /* bit positions per build; 50 codes of 20 bits end below it */
+constexpr uint32_t SCAN_ROWS = SCAN_MAX_SPAN / 64;
+constexpr uint32_t GROUP_SYMS = 50;
+constexpr uint32_t MAX_SCAN_GROUPS = 18002;     /* 900 100 symbols: more than any block that k_mtf accepts */
+constexpr uint32_t GPOS_STRIDE = 18048;         /* u32 per block */
+constexpr uint32_t SCAN_RING_WORDS = 128;      /* + 64 mirrored words, so that two consecutive words never wrap */
+constexpr uint32_t LEN_STOP = 0x80u;            /* length-table flag: the code is the end-of-block symbol */
+constexpr uint32_t SYM_THREADS = 256;           /* groups per k_hsym workgroup */
+
+/** Decode tables of one block, written by k_hscan and read by every k_hsym workgroup of the block. */
+struct alignas( 16 ) HuffTables
+{
+    uint16_t lut[6][SCAN_LUT_SIZE];   /* {len:5, sym:9 << 5} of the code that starts an index; 0: longer than the index / none */
+    uint16_t perm[6][264];            /* symbols in canonical order */
+    uint32_t first[6][24];            /* first code of length l */
+    uint32_t count[6][24];            /* codes of length l */
+    uint32_t offs[6][24];             /* index into perm of the first code of length l */
+    uint32_t minmax[8];               /* minLen | maxLen << 8 per table */
+};
+static_assert( sizeof( HuffTables ) % 16 == 0 );
+
+/** Per-block hand-off from k_hscan to k_hsym. */
+struct ScanMeta
+{
+    uint64_t pos_base;      /* absolute bit position that relative position 0 stands for (multiple of 32) */
+    uint32_t size_bits;     /* end of the input, relative (clamped) */
+    uint32_t n_groups;      /* groups whose start is known */
+    uint32_t terminal;      /* 1: the last group runs into end-of-block / an error and its lane finishes the record */
+    uint32_t symbol_count;
+    uint32_t pad[2];
+};
+
+struct ScanShared
+{
+    uint8_t  lenlut[6][SCAN_LUT_SIZE];   /* code length per index (| LEN_STOP: end-of-block), 0 = longer than the index or no code */
+    uint32_t limit[6][24];               /* [t][l]: (first + count) << (20 - l), 0 outside [minLen, maxLen] */
+    uint32_t eob_lo[6], eob_hi[6];       /* 20-bit windows that start with the end-of-block code: [lo, hi) */
+    uint32_t ring[SCAN_RING_WORDS + 64]; /* stream words around the current position; [128, 192) mirrors [0, 64) */
+    uint32_t minmax[6];
+    union alignas( 16 ) {
+        struct {
+            uint16_t lut[SCAN_LUT_SIZE];      /* first: copied out in 16-byte units */
+            uint32_t first[24], count[24], offs[24], running[24];
+            uint16_t perm[264];
+            uint16_t bitmap[16];
+            uint8_t  lens[264];
+            uint8_t  sym_to_byte[256];
+        } build;
+        struct {
+            uint16_t a[SCAN_MAX_SPAN + 16], b[SCAN_MAX_SPAN + 16], c[SCAN_MAX_SPAN + 16];
+        } lev;
+    };
+};
+
+/** J1 (successor of every bit position under table t) and its doublings J2 .. J32 over R rows of 64 positions that
+ * start at relative bit position p.  Afterwards sh.lev.b = J2, sh.lev.c = J16, sh.lev.a = J32 (only entry 0 if `firstOnly`:
+ * a single group is chased from position 0).  Entries are BYTE offsets into these u16 arrays (2 x position), so that a
+ * round of doubling is one ds_read + one ds_write per row: 2 i' for the next position, OUT = 2 S beyond the span, TERM =
+ * 2 S + 2 for a position whose code is the end-of-block symbol, matches no code or ends behind the input.  OUT and TERM
+ * are entries that point to themselves (written by the caller), i.e. absorbing under doubling. */
+template<uint32_t R, bool NEAR_END>
+__device__ __forceinline__ void
+scan_build( ScanShared& sh, uint32_t t, uint32_t p, uint32_t S, uint32_t sizeBits, const uint32_t ( &lim )[10],
+            uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane )
+{
+    const uint8_t* const A = reinterpret_cast<const uint8_t*>( sh.lev.a );
+    const uint8_t* const B = reinterpret_cast<const uint8_t*>( sh.lev.b );
+    const uint8_t* const C = reinterpret_cast<const uint8_t*>( sh.lev.c );
+    const uint8_t* const lenlut = sh.lenlut[t];
+    const uint32_t OUT = 2 * S, TERM = 2 * S + 2;
+    uint32_t own[R], v20s[R];
+    bool anyLong = false;
+#pragma unroll
+    for ( uint32_t r = 0; r < R; ++r ) {
+        const uint32_t a = p + 64 * r + lane;
+        const uint32_t* const w = sh.ring + ( ( a >> 5 ) & ( SCAN_RING_WORDS - 1 ) );
+        const uint32_t hi = w[0], lo = w[1];   /* one ds_read2_b32: the ring is mirrored behind its end */
+        const uint32_t bits32 = (uint32_t)( ( ( ( (uint64_t)hi << 32 ) | lo ) << ( a & 31u ) ) >> 32 );
+        v20s[r] = bits32 >> 12;
+        own[r] = lenlut[bits32 >> ( 32 - SCAN_LUT_BITS )];
+    }
+#pragma unroll
+    for ( uint32_t r = 0; r < R; ++r ) anyLong |= own[r] == 0;
+    if ( __ballot( anyLong ) != 0 ) {
+        /* longer than the index bits: canonical codes, the first length whose range end exceeds the window
+         * (decodeLong, HuffmanCodingShortBitsCached.hpp:117-150); 21: no code matches */
+#pragma unroll
+        for ( uint32_t r = 0; r < R; ++r ) {
+            uint32_t ll = 11;
+#pragma unroll
+            for ( uint32_t l = 0; l < 10; ++l ) ll += v20s[r] >= lim[l] ? 1u : 0u;
+            const bool stop = ( ll > 20 ) | ( ( v20s[r] >= eobLo ) & ( v20s[r] < eobHi ) );
+            own[r] = own[r] == 0 ? ( stop ? LEN_STOP : ll ) : own[r];
+        }
+    }
+#pragma unroll
+    for ( uint32_t r = 0; r < R; ++r ) {
+        const uint32_t i = 64 * r + lane;
+        const uint32_t len = own[r];
+        bool stop = len >= LEN_STOP;
+        if ( NEAR_END ) stop |= p + i + ( len & 31u ) > sizeBits;
+        const uint32_t next = 2 * ( i + len ) < OUT ? 2 * ( i + len ) : OUT;
+        own[r] = stop ? TERM : next;
+        sh.lev.a[i] = (uint16_t)own[r];
+    }
+    wave_sync();
+    /* one round of doubling: own[r] = src[own[r]], the same into dst */
+#define SCAN_LEVEL( src, dst ) \
+    _Pragma( "unroll" ) for ( uint32_t r = 0; r < R; ++r ) own[r] = *reinterpret_cast<const uint16_t*>( src + own[r] ); \
+    _Pragma( "unroll" ) for ( uint32_t r = 0; r < R; ++r ) sh.lev.dst[64 * r + lane] = (uint16_t)own[r]; \
+    wave_sync();
+    SCAN_LEVEL( A, b )   /* J2 -> b (kept) */
+    SCAN_LEVEL( B, c )   /* J4 */
+    SCAN_LEVEL( C, a )   /* J8 */
+    SCAN_LEVEL( A, c )   /* J16 -> c (kept) */
+    if ( firstOnly ) {
+        const uint32_t j32 = *reinterpret_cast<const uint16_t*>( C + own[0] );
+        if ( lane == 0 ) sh.lev.a[0] = (uint16_t)j32;
+        wave_sync();
+    } else {
+        SCAN_LEVEL( C, a )   /* J32 -> a (kept) */
+    }
+#undef SCAN_LEVEL
+}
+
+__global__ __launch_bounds__( 64 ) void
+k_hscan( const uint32_t* __restrict__ in_words,
+         uint64_t                     in_size_bytes,
+         const uint64_t* __restrict__ offsets,
+         BlockMeta* __restrict__      meta,
+         HuffMeta* __restrict__       hmeta,
+         ScanMeta* __restrict__       smeta,
+         uint8_t*                     sel_buf,
+         uint8_t* __restrict__        stb_buf,
+         HuffTables* __restrict__     tab_buf,
+         uint32_t* __restrict__       gpos_buf,
+         uint32_t                     n_blocks,
+         const uint32_t* __restrict__ order )
+{
+    __shared__ ScanShared sh;
+    const uint32_t slot = blockIdx.x;
+    if ( slot >= n_blocks ) return;
+    const uint32_t b = sfl( order[slot] );
+    const uint32_t lane = threadIdx.x & 63;
+    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
+    uint32_t* const gpos = gpos_buf + (size_t)b * GPOS_STRIDE;
+    HuffTables* const tabs = tab_buf + b;
+
+    const uint64_t start = offsets[b];
+    BitRd br;
+    br.init( in_words, in_size_bytes, start );
+
+    int32_t status = ST_OK;
+    uint32_t headerCrc = 0, origPtr = 0;
+    int32_t isEos = 0, isEof = 0;
+    uint64_t encSize = 0;
+    uint32_t symbolCount = 0, groupCount = 0, nSel = 0;
+    uint32_t active = 0;
+    uint32_t nGroups = 0, terminal = 0;
+    uint64_t posBase = 0;
+    uint32_t sizeBits = 0;
+
+#define FAIL( code ) do { status = br.eof ? (int32_t)ST_EOF : (int32_t)( code ); goto finish; } while ( 0 )
+
+    /* ---- Block::readBlockHeader, bzip2.hpp:479-523 ---- */
+    if ( start > br.size_bits ) {
+        br.eof = true;
+        FAIL( ST_EOF );
+    }
+    {
+        const uint64_t hi = br.read( 24 );
+        const uint64_t lo = br.read( 24 );
+        const uint64_t magic = ( hi << 24 ) | lo;
+        headerCrc = br.read( 32 );
+        if ( br.eof ) {
+            headerCrc = 0;   /* the reference's read throws before anything is assigned */
+            FAIL( ST_EOF );
+        }
+        if ( magic == 0x177245385090ULL ) {
+            isEos = 1;
+            const uint32_t inByte = (uint32_t)( br.pos & 7 );
+            if ( inByte > 0 ) {
+                br.read( 8 - inByte );
+                if ( br.eof ) FAIL( ST_EOF );
+            }
+            encSize = br.pos - start;
+            isEof = br.pos >= br.size_bits;
+            goto finish;
+        }
+        if ( magic != 0x314159265359ULL ) FAIL( ST_BAD_MAGIC );
+        const uint32_t randomized = br.read( 1 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( randomized ) FAIL( ST_RANDOMIZED );
+        origPtr = br.read( 24 );
+        if ( br.eof ) {
+            origPtr = 0;
+            FAIL( ST_EOF );
+        }
+        if ( origPtr > MAX_N ) FAIL( ST_ORIGPTR_RANGE );
+    }
+
+    /* ---- Block::readSymbolMaps, bzip2.hpp:526-571 ---- */
+    {
+        const uint32_t used = br.read( 16 );
+        for ( uint32_t v = lane; v < 256; v += 64 ) sh.build.sym_to_byte[v] = 0;   /* fresh Block: zero-initialised */
+        for ( int i = 0; i < 16; ++i ) {
+            uint32_t bm = 0;
+            if ( used & ( 1u << ( 15 - i ) ) ) {
+                bm = br.read( 16 );
+            }
+            if ( lane == 0 ) sh.build.bitmap[i] = (uint16_t)bm;
+        }
+        wave_sync();
+        uint32_t total = 0;
+        for ( int g = 0; g < 16; ++g ) total += __popc( sh.build.bitmap[g] );
+        symbolCount = total;
+        for ( uint32_t v = lane; v < 256; v += 64 ) {
+            const uint32_t g = v >> 4, j = v & 15;
+            const uint32_t bm = sh.build.bitmap[g];
+            if ( bm & ( 1u << ( 15 - j ) ) ) {
+                uint32_t rank = 0;
+                for ( uint32_t gg = 0; gg < g; ++gg ) rank += __popc( sh.build.bitmap[gg] );
+                rank += j == 0 ? 0 : __popc( bm >> ( 16 - j ) );
+                sh.build.sym_to_byte[rank] = (uint8_t)v;
+            }
+        }
+        wave_sync();
+        if ( br.eof ) FAIL( ST_EOF );
+        reinterpret_cast<uint32_t*>( stb_buf + (size_t)b * 256 )[lane] =
+            reinterpret_cast<const uint32_t*>( sh.build.sym_to_byte )[lane];
+    }
+
+    /* ---- Block::readSelectors, bzip2.hpp:574-637 ---- */
+    {
+        groupCount = br.read( 3 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( groupCount < 2 || groupCount > 6 ) FAIL( ST_GROUP_COUNT );
+        nSel = br.read( 15 );
+        if ( br.eof ) FAIL( ST_EOF );
+        if ( nSel == 0 ) FAIL( ST_SELECTOR_COUNT );
+        uint32_t mtfsel = 0x543210u;   /* nibble k = entry k */
+        uint32_t packed = 0;
+        for ( uint32_t i = 0; i < nSel; ++i ) {
+            br.refill();
+            if ( br.pos + 6 > br.size_bits ) {   /* peek<6> throws at EOF, BitReader.hpp:458-460 */
+                br.eof = true;
+                FAIL( ST_EOF );
+            }
+            const uint32_t bits6 = br.peek( 6 );
+            const uint32_t j = __clz( ~( bits6 << 26 ) );   /* leading ones, 6 if all set */
+            br.skip( j + 1 );
+            if ( j >= groupCount ) FAIL( ST_SELECTOR_UNARY );
+            const uint32_t shj = 4 * j;
+            const uint32_t val = ( mtfsel >> shj ) & 0xFu;
+            const uint32_t low = mtfsel & ( ( 1u << shj ) - 1u );
+            const uint32_t highMask = ~( ( 16u << shj ) - 1u );
+            mtfsel = ( mtfsel & highMask ) | ( low << 4 ) | val;
+            packed |= val << ( 8 * ( i & 3 ) );
+            if ( ( i & 3 ) == 3 || i + 1 == nSel ) {
+                if ( lane == 0 ) *reinterpret_cast<uint32_t*>( sel + ( i & ~3u ) ) = packed;
+                packed = 0;
+            }
+        }
+    }
+
+    /* ---- Block::readTrees, bzip2.hpp:644-685, and the canonical tables, one table at a time ---- */
+    {
+        const uint32_t symCount = symbolCount + 2;
+        const uint32_t eob = symbolCount + 1;
+        for ( uint32_t t = 0; t < groupCount; ++t ) {
+            uint32_t hh = br.read( 5 );
+            if ( br.eof ) FAIL( ST_EOF );
+            for ( uint32_t s = 0; s < symCount; ++s ) {
+                for ( ;; ) {
+                    if ( hh - 1u > 19u ) FAIL( ST_CODE_LENGTH );
+                    br.refill();
+                    const uint32_t b2 = br.peek( 2 );
+                    if ( b2 < 2 ) {
+                        if ( br.pos + 1 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+                        br.skip( 1 );
+                        break;
+                    }
+                    if ( br.pos + 2 > br.size_bits ) { br.eof = true; FAIL( ST_EOF ); }
+                    hh += b2 == 2 ? 1u : 0xFFFFFFFFu;
+                    br.skip( 2 );
+                }
+                if ( lane == 0 ) sh.build.lens[s] = (uint8_t)hh;
+            }
+            /* the reference builds (and checks) the coding of a group before it reads the next group's lengths
+             * (bzip2.hpp:679-683): an over-subscribed set here wins over a bad length further on */
+            wave_sync();
+            uint32_t c = 0;
+            if ( lane >= 1 && lane <= 20 ) {
+                for ( uint32_t s = 0; s < symCount; ++s ) c += sh.build.lens[s] == lane;
+            }
+            if ( lane < 24 ) sh.build.count[lane] = c;
+            wave_sync();
+            uint32_t minLen = 0, maxLen = 0;
+            for ( uint32_t l = 1; l <= 20; ++l ) {
+                if ( sh.build.count[l] != 0 ) {
+                    if ( minLen == 0 ) minLen = l;
+                    maxLen = l;
+                }
+            }
+            {
+                uint32_t unused = 1u << minLen;
+                bool bad = false;
+                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
+                    const uint32_t f = sh.build.count[l];
+                    if ( f > unused ) { bad = true; break; }
+                    unused = ( unused - f ) * 2u;
+                }
+                if ( bad ) FAIL( ST_HUFFMAN_LENGTHS );
+            }
+            if ( lane == 0 ) {
+                uint32_t minCode = 0, sum = 0;
+                for ( uint32_t l = 0; l < 24; ++l ) { sh.build.first[l] = 0; sh.build.offs[l] = 0; }
+                for ( uint32_t l = minLen; l <= maxLen; ++l ) {
+                    minCode = ( minCode + ( l > minLen ? sh.build.count[l - 1] : 0u ) ) << 1;
+                    if ( l == minLen ) minCode = 0;
+                    sh.build.first[l] = minCode;
+                    sh.build.offs[l] = sum;
+                    sh.build.running[l] = sum;
+                    sum += sh.build.count[l];
+                }
+                sh.minmax[t] = minLen | ( maxLen << 8 );
+            }
+            wave_sync();
+            for ( uint32_t base = 0; base < symCount; base += 64 ) {
+                const uint32_t s = base + lane;
+                const bool valid = s < symCount;
+                const uint32_t len = valid ? sh.build.lens[s] : 0u;
+                const uint64_t same = match_any( len, 5, valid );
+                const uint32_t rank = popc_below( same, lane );
+                uint32_t basePos = 0;
+                if ( valid ) basePos = sh.build.running[len];
+                if ( valid ) sh.build.perm[basePos + rank] = (uint16_t)s;
+                wave_sync();
+                if ( valid && rank == 0 ) sh.build.running[len] = basePos + (uint32_t)__popcll( same );
+                wave_sync();
+            }
+            if ( lane < 24 ) {
+                const bool in = lane >= minLen && lane <= maxLen;
+                sh.limit[t][lane] = in ? ( ( sh.build.first[lane] + sh.build.count[lane] ) << ( 20 - lane ) ) : 0u;
+            }
+            if ( lane == 0 ) {
+                /* canonical order is (length, symbol): the end-of-block symbol, the highest, is the last code of its length */
+                const uint32_t le = sh.build.lens[eob];
+                const uint32_t hi = ( sh.build.first[le] + sh.build.count[le] ) << ( 20 - le );
+                sh.eob_hi[t] = hi;
+                sh.eob_lo[t] = hi - ( 1u << ( 20 - le ) );
+            }
+            const uint32_t lutMax = maxLen < SCAN_LUT_BITS ? maxLen : SCAN_LUT_BITS;
+            for ( uint32_t e = lane; e < SCAN_LUT_SIZE; e += 64 ) {
+                uint32_t val = 0;
+                for ( uint32_t l = minLen; l <= lutMax; ++l ) {
+                    const uint32_t code = e >> ( SCAN_LUT_BITS - l );
+                    const uint32_t d = code - sh.build.first[l];
+                    if ( d < sh.build.count[l] ) {
+                        val = l | ( (uint32_t)sh.build.perm[sh.build.offs[l] + d] << 5 );
+                        break;
+                    }
+                }
+                sh.build.lut[e] = (uint16_t)val;
+                sh.lenlut[t][e] = (uint8_t)( ( val & 31u ) | ( ( val >> 5 ) == eob && val != 0 ? LEN_STOP : 0u ) );
+            }
+            wave_sync();
+            /* the block's tables for k_hsym */
+            {
+                const uint4* const src = reinterpret_cast<const uint4*>( sh.build.lut );
+                uint4* const dst = reinterpret_cast<uint4*>( tabs->lut[t] );
+                for ( uint32_t k = lane; k < SCAN_LUT_SIZE * 2 / 16; k += 64 ) dst[k] = src[k];
+                for ( uint32_t k = lane; k < 264; k += 64 ) tabs->perm[t][k] = k < symCount ? sh.build.perm[k] : (uint16_t)0;
+                if ( lane < 24 ) {
+                    tabs->first[t][lane] = sh.build.first[lane];
+                    tabs->count[t][lane] = lane <= 20 ? sh.build.count[lane] : 0u;
+                    tabs->offs[t][lane] = sh.build.offs[lane];
+                }
+                if ( lane == 0 ) tabs->minmax[t] = minLen | ( maxLen << 8 );
+            }
+            wave_sync();
+        }
+    }
+    active = 1;
+
+    /* ---- where every 50-symbol group of Block::readBlockData's loop (bzip2.hpp:709-723) starts ---- */
+    {
+        /* Bit positions are 32-bit and relative to the word that holds the first symbol bit, as in k_huff. */
+        posBase = br.pos & ~31ull;
+        const uint32_t* const words = in_words + ( posBase >> 5 );
+        const uint64_t wordsLeft = ( ( in_size_bytes + 3 ) >> 2 ) - ( posBase >> 5 );
+        const uint32_t nWords = wordsLeft < 0x08000000ull ? (uint32_t)wordsLeft : 0x08000000u;
+        sizeBits = br.size_bits - posBase < 0xFFFF0000ull ? (uint32_t)( br.size_bits - posBase ) : 0xFFFF0000u;
+        uint32_t p = (uint32_t)( br.pos - posBase );
+        uint32_t g = 0;
+        __threadfence_block();   /* selectors written above are read back below */
+
+        /* stream ring: words [wHi - 128, wHi) are in sh.ring, the next 64 are on their way in `pend` */
+        uint32_t wHi = 0;
+        uint32_t pend = lane < nWords ? words[lane] : 0u;
+        /* selectors of groups [64 k, 64 k + 64), one per lane, the next 64 on their way */
+        uint32_t selV = sel[lane];
+        uint32_t selPend = sel[64 + lane];
+        /* per-table estimate of a group's length in bits, lane t = table t; 0 = not seen yet (full span) */
+        uint32_t estV = 0;
+        uint32_t gposV = 0;
+        uint32_t lastS = 0, lastT = 0xFFFFFFFFu;
+        uint32_t lim[10] = {};
+        uint32_t eobLo = 0, eobHi = 0;
+        bool forceFull = false;
+
+        for ( ;; ) {
+            if ( g >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
+            if ( g >= MAX_SCAN_GROUPS ) { status = ST_DATA_OVERFLOW; break; }
+            /* stream words up to (p + SCAN_MAX_SPAN + 64) >> 5 */
+            while ( ( p >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
+                sh.ring[( wHi & ( SCAN_RING_WORDS - 1 ) ) + lane] = pend;
+                if ( ( wHi & ( SCAN_RING_WORDS - 1 ) ) == 0 ) sh.ring[SCAN_RING_WORDS + lane] = pend;   /* mirror */
+                wHi += 64;
+                pend = wHi + lane < nWords ? words[wHi + lane] : 0u;
+            }
+            /* this group's table and how many of the following groups (of this window of 64) use it as well */
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane( (int)selV, g & 63u );
+            uint32_t runLen;
+            {
+                const uint64_t same = __ballot( selV == t ) >> ( g & 63u );   /* bit 0 = this group */
+                runLen = (uint32_t)__builtin_ctzll( ~same );                    /* >= 1; 64 if all the rest match */
+                if ( runLen > 64u - ( g & 63u ) ) runLen = 64u - ( g & 63u );
+                if ( runLen > nSel - g ) runLen = nSel - g;
+                if ( runLen > MAX_SCAN_GROUPS - g ) runLen = MAX_SCAN_GROUPS - g;
+            }
+            if ( t != lastT ) {
+                /* range ends of the long codes of this table, flat beyond its longest code: a 20-bit window v holds a code
+                 * of length 11 + #{ l : v >= lim[l] }, none if that comes to 21 */
+                const uint32_t mx = sfl( sh.minmax[t] ) >> 8;
+                const uint32_t limV = sh.limit[t][lane < mx ? ( lane < 24 ? lane : 23 ) : mx];
+#pragma unroll
+                for ( uint32_t l = 0; l < 10; ++l ) lim[l] = (uint32_t)__builtin_amdgcn_readlane( (int)limV, 11 + l );
+                eobLo = sfl( sh.eob_lo[t] );
+                eobHi = sfl( sh.eob_hi[t] );
+                lastT = t;
+            }
+            const uint32_t est = (uint32_t)__builtin_amdgcn_readlane( (int)estV, t );
+            uint32_t S = SCAN_MAX_SPAN, m = 1;
+            if ( est != 0 && !forceFull ) {
+                const uint32_t need = est + ( est >> 3 ) + 16;   /* a group of this table: last one + 12 % + 16 bits */
+                m = ( SCAN_MAX_SPAN - 24 ) / need;
+                if ( m > runLen ) m = runLen;
+                if ( m < 1 ) m = 1;
+                S = ( m * need + 24 + 63 ) & ~63u;
+                if ( S > SCAN_MAX_SPAN ) S = SCAN_MAX_SPAN;
+            }
+            forceFull = false;
+            /* the builds are statically unrolled per row count: round the span up to the next instance; close to the end
+             * of the input every position checks that its code ends inside (one instance: the full span) */
+            const bool nearEnd = p + SCAN_MAX_SPAN + 32 > sizeBits;
+            uint32_t rows = nearEnd ? SCAN_ROWS : S >> 6;
+            rows = rows <= 6 ? rows : ( rows <= 8 ? 8u : ( rows <= 10 ? 10u : ( rows <= 12 ? 12u : 16u ) ) );
+            S = rows << 6;
+            if ( S != lastS ) {
+                /* OUT = 2 S and TERM = 2 S + 2 point to themselves in all three arrays */
+                if ( lane < 2 ) {
+                    const uint16_t v = (uint16_t)( 2 * ( S + lane ) );
+                    sh.lev.a[S + lane] = v; sh.lev.b[S + lane] = v; sh.lev.c[S + lane] = v;
+                }
+                lastS = S;
+            }
+            const bool one = m == 1;
+            if ( nearEnd ) {
+                scan_build<16, true>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane );
+            } else {
+                switch ( rows ) {
+                case 1: scan_build<1, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 2: scan_build<2, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 3: scan_build<3, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 4: scan_build<4, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 5: scan_build<5, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 6: scan_build<6, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 8: scan_build<8, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 10: scan_build<10, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                case 12: scan_build<12, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                default: scan_build<16, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
+                }
+            }
+
+            /* chase: 32 + 16 + 2 symbols per group; x and the entries are byte offsets (2 x position) */
+            const uint8_t* const J32 = reinterpret_cast<const uint8_t*>( sh.lev.a );
+            const uint8_t* const J16 = reinterpret_cast<const uint8_t*>( sh.lev.c );
+            const uint8_t* const J2 = reinterpret_cast<const uint8_t*>( sh.lev.b );
+            uint32_t x = 0, done = 0;
+            bool stopAll = false;
+            for ( uint32_t j = 0; j < m; ++j ) {
+                const uint32_t q = *reinterpret_cast<const uint16_t*>( J32 + x );
+                const uint32_t r16 = *reinterpret_cast<const uint16_t*>( J16 + q );
+                const uint32_t u = sfl( *reinterpret_cast<const uint16_t*>( J2 + r16 ) );
+                if ( u == 2 * S ) {                   /* left the span: again from here, the first group with the full span */
+                    forceFull = j == 0;
+                    break;
+                }
+                const uint32_t gg = g + j;
+                gposV = lane == ( gg & 63u ) ? p + ( x >> 1 ) : gposV;
+                if ( ( gg & 63u ) == 63u ) gpos[( gg & ~63u ) + lane] = gposV;
+                ++done;
+                if ( u == 2 * S + 2 ) {               /* end-of-block, no code or end of input inside this group */
+                    terminal = 1;
+                    stopAll = true;
+                    break;
+                }
+                {
+                    const uint32_t d = ( u - x ) >> 1;
+                    const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane( (int)estV, t );
+                    const uint32_t upd = ( cur == 0 || d > cur ) ? d : cur - ( ( cur - d ) >> 2 );
+                    estV = lane == t ? upd : estV;
+                }
+                x = u;
+            }
+            if ( ( ( g + done ) ^ g ) & ~63u ) {      /* next window of 64 selectors */
+                selV = selPend;
+                selPend = sel[( ( g + done ) & ~63u ) + 64 + lane];   /* may read past the block's selectors: never used */
+            }
+            g += done;
+            p += x >> 1;
+            if ( stopAll ) break;
+        }
+        nGroups = g;
+        if ( ( g & 63u ) != 0 && lane < ( g & 63u ) ) gpos[( g & ~63u ) + lane] = gposV;
+    }
+
+finish:
+#undef FAIL
+    if ( lane == 0 ) {
+        const uint32_t fullGroups = terminal ? nGroups - 1 : nGroups;
+        BlockMeta mt;
+        mt.enc_off = start;
+        mt.enc_size = encSize;
+        mt.decoded_size = 0;
+        mt.out_off = 0;
+        mt.header_crc = headerCrc;
+        mt.computed_crc = 0xFFFFFFFFu;
+        mt.n = 0;
+        mt.orig_ptr = origPtr;
+        mt.nsym = fullGroups * GROUP_SYMS;    /* k_hsym's last lane finishes nsym, enc_size and status of a terminal group */
+        mt.is_eos = isEos;
+        mt.is_eof = isEof;
+        mt.status = status;
+        mt.seg_stride = MIN_SEG_STRIDE;
+        mt.nseg = 0;
+        mt.walk_ok = 0;
+        mt.cycle_len = 0;
+        mt.nchain = 0;
+        mt.pad = 0;
+        meta[b] = mt;
+        HuffMeta hm;
+        hm.n_stored = fullGroups * GROUP_SYMS;
+        hm.symbol_count = symbolCount;
+        hm.status = status;
+        hm.active = active;
+        hmeta[b] = hm;
+        ScanMeta sm;
+        sm.pos_base = posBase;
+        sm.size_bits = sizeBits;
+        sm.n_groups = nGroups;
+        sm.terminal = terminal;
+        sm.symbol_count = symbolCount;
+        sm.pad[0] = sm.pad[1] = 0;
+        smeta[b] = sm;
+    }
+}
+
+/* ============================================================================================================= */
+
+struct alignas( 16 ) SymShared
+{
+    HuffTables tabs;
+    uint16_t stage[SYM_THREADS * GROUP_SYMS];
+};
+
+__global__ __launch_bounds__( SYM_THREADS ) void
+k_hsym( const uint32_t* __restrict__   in_words,
+        BlockMeta* __restrict__        meta,
+        HuffMeta* __restrict__         hmeta,
+        const ScanMeta* __restrict__   smeta,
+        const uint8_t* __restrict__    sel_buf,
+        const HuffTables* __restrict__ tab_buf,
+        const uint32_t* __restrict__   gpos_buf,
+        uint16_t* __restrict__         sym_buf )
+{
+    __shared__ SymShared sh;
+    const uint32_t b = blockIdx.y;
+    const ScanMeta sm = smeta[b];
+    const uint32_t g0 = blockIdx.x * SYM_THREADS;
+    if ( g0 >= sm.n_groups ) return;
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint4* const src = reinterpret_cast<const uint4*>( tab_buf + b );
+        uint4* const dst = reinterpret_cast<uint4*>( &sh.tabs );
+        for ( uint32_t k = tid; k < sizeof( HuffTables ) / 16; k += SYM_THREADS ) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const uint32_t gi = g0 + tid;
+    const uint32_t eob = sm.symbol_count + 1;
+    if ( gi < sm.n_groups ) {
+        const uint32_t t = sel_buf[(size_t)b * SEL_STRIDE + gi];
+        const uint32_t* const words = in_words + ( sm.pos_base >> 5 );
+        uint32_t pos = gpos_buf[(size_t)b * GPOS_STRIDE + gi];
+        const bool last = sm.terminal && gi + 1 == sm.n_groups;
+        /* bit buffer: `have` valid bits left-aligned in buf */
+        uint32_t w = pos >> 5;
+        uint64_t buf = ( ( (uint64_t)words[w] << 32 ) | words[w + 1] ) << ( pos & 31u );
+        uint32_t have = 64 - ( pos & 31u );
+        w += 2;
+        const uint16_t* const lut = sh.tabs.lut[t];
+        const uint32_t mm = sh.tabs.minmax[t];
+        const uint32_t maxLen = mm >> 8;
+        uint16_t* const out = sh.stage + tid * GROUP_SYMS;
+        uint32_t cnt = 0;
+        int32_t status = ST_OK;
+        bool finished = false;
+        for ( uint32_t j = 0; j < GROUP_SYMS; ++j ) {
+            if ( have <= 32 ) {
+                buf |= (uint64_t)words[w] << ( 32 - have );   /* the input copy is zero padded */
+                have += 32;
+                ++w;
+            }
+            uint32_t e = lut[(uint32_t)( buf >> ( 64 - SCAN_LUT_BITS ) )];
+            uint32_t len = e & 31u, sym = e >> 5;
+            if ( len == 0 ) {
+                const uint32_t v20 = (uint32_t)( buf >> 44 );
+                for ( uint32_t l = SCAN_LUT_BITS + 1; l <= maxLen; ++l ) {
+                    const uint32_t d = ( v20 >> ( 20 - l ) ) - sh.tabs.first[t][l];
+                    if ( d < sh.tabs.count[t][l] ) {
+                        len = l;
+                        sym = sh.tabs.perm[t][sh.tabs.offs[t][l] + d];
+                        break;
+                    }
+                }
+            }
+            if ( last ) {
+                /* the rules of the bit reader and of the decoder at the end of the input (oracle: huff_decode) */
+                if ( len == 0 ) {
+                    status = pos + maxLen > sm.size_bits ? ST_EOF : ST_INVALID_CODE;
+                    break;
+                }
+                if ( pos + len > sm.size_bits ) {
+                    status = ST_EOF;
+                    break;
+                }
+            }
+            pos += len;
+            buf <<= len;
+            have -= len;
+            if ( last && sym == eob ) {
+                finished = true;
+                break;
+            }
+            out[j] = (uint16_t)sym;
+            ++cnt;
+        }
+        if ( last ) {
+            const uint32_t stored = gi * GROUP_SYMS + cnt;
+            if ( !finished && status == ST_OK ) status = ST_INVALID_CODE;   /* unreachable: k_hscan saw the group end early */
+            hmeta[b].n_stored = stored;
+            hmeta[b].status = status;
+            meta[b].nsym = stored + ( finished ? 1u : 0u );
+            meta[b].status = status;
+            meta[b].enc_size = sm.pos_base + pos - meta[b].enc_off;
+        }
+    }
+    __syncthreads();
+    /* stage -> memory: the groups of a workgroup are one contiguous piece of the symbol buffer */
+    {
+        const uint32_t nHere = sm.n_groups - g0 < SYM_THREADS ? sm.n_groups - g0 : SYM_THREADS;
+        const uint32_t units = ( nHere * GROUP_SYMS * 2 + 15 ) / 16;   /* the symbol buffer is padded */
+        uint4* const dst = reinterpret_cast<uint4*>( sym_buf + (size_t)b * SYM_STRIDE + (size_t)g0 * GROUP_SYMS );
+        const uint4* const src = reinterpret_cast<const uint4*>( sh.stage );
+        for ( uint32_t k = tid; k < units; k += SYM_THREADS ) dst[k] = src[k];
+    }
+}
+}  // namespace bz2gpu

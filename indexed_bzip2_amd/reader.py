@@ -3,8 +3,12 @@
 Same names and argument meaning: open(), IndexedBzip2File(io.BufferedReader), IndexedBzip2FileRaw(io.RawIOBase) with
 tell_compressed, block_offsets, set_block_offsets, block_offsets_complete, available_block_offsets, size,
 join_threads.  The C++ ParallelBZ2Reader the Cython classes wrap is replaced by mi355x_bz2_reader_* (C ABI), whose
-blocks are decoded on the GPU.  `parallelization` = number of blocks kept in flight per GPU batch (0 = default);
-there is no serial CPU reader, so every value uses the GPU path.
+blocks are decoded on the GPU.  `parallelization` keeps the reference's meaning and default
+(indexed_bzip2.pyx:293, 321, 340): 1 (default) = no parallelism, i.e. one block per GPU launch and -- like the serial
+BZ2Reader that the reference selects for 1 -- the stream CRC of every end-of-stream block is verified
+(BZ2Reader.hpp:406-416); 0 = as much as the machine wants (reference: all cores; here: the default batch of 512
+blocks); N > 1 = N blocks per GPU batch, no stream-CRC check (ParallelBZ2Reader never checks it).  There is no CPU
+reader: every value decodes on the GPU.
 """
 import ctypes
 import builtins
@@ -31,7 +35,7 @@ def _is_file_object(file):
 class _IndexedBzip2FileParallel:
     """Mirror of cdef class _IndexedBzip2FileParallel (indexed_bzip2.pyx:186-288)."""
 
-    def __init__(self, file, parallelization=0, device=-1):
+    def __init__(self, file, parallelization=1, device=-1):
         if not isinstance(parallelization, int):
             raise TypeError(f"Parallelization argument must be an integer not '{parallelization}'!")
         self._h = ctypes.c_void_p()
@@ -179,7 +183,7 @@ class _IndexedBzip2FileParallel:
 class IndexedBzip2FileRaw(io.RawIOBase):
     """indexed_bzip2.pyx:290-317"""
 
-    def __init__(self, filename, parallelization=0, device=-1):
+    def __init__(self, filename, parallelization=1, device=-1):
         self.bz2reader = _IndexedBzip2FileParallel(filename, parallelization, device)
         self.name = filename
         self.mode = "rb"
@@ -203,7 +207,7 @@ class IndexedBzip2FileRaw(io.RawIOBase):
 class IndexedBzip2File(io.BufferedReader):
     """indexed_bzip2.pyx:320-337"""
 
-    def __init__(self, filename, parallelization=0, device=-1):
+    def __init__(self, filename, parallelization=1, device=-1):
         fobj = IndexedBzip2FileRaw(filename, parallelization, device)
         self.bz2reader = fobj.bz2reader
 
@@ -224,10 +228,12 @@ class IndexedBzip2File(io.BufferedReader):
 builtins_open = builtins.open
 
 
-def open(filename, parallelization=0, device=-1):
+def open(filename, parallelization=1, device=-1):
     """
     filename: can be a file path, a file descriptor, or a file object
               with suitable read, seekable, seek, and tell methods.          (indexed_bzip2.pyx:340-345)
+    parallelization: 1 (default, as in the reference) = block by block with the stream-CRC check of the reference's
+              serial reader; 0 = default GPU batch (512 blocks); N = N blocks per GPU batch.
     """
     return IndexedBzip2File(filename, parallelization, device)
 

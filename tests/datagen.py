@@ -61,6 +61,71 @@ def compress(data, level=9):
     return bz2.compress(data, level)
 
 
+def enwik_like(n=10_000_000, seed=0xE8E8):
+    """BASELINE config 1 / SURVEY 8(d): "enwik-style" text -- XML-ish wiki page markup around Zipf-distributed words
+    from the committed list tests/golden/wordlist.txt, seeded xorshift-style generator (numpy PCG64 seeded with 0xE8E8;
+    enwik8 itself is not available offline).  At `bzip2 -1` 10 000 000 bytes give ~100 blocks of 100 kB."""
+    import os
+    r = rng(seed)
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "wordlist.txt"), "rb") as f:
+        words = f.read().split()
+    out = []
+    size = 0
+    page = 0
+    while size < n + 4096:
+        page += 1
+        k = int(r.integers(150, 2500))
+        idx = ( r.zipf(1.2, k) - 1 ) % len(words)   # the heavy tail is folded over the whole list
+        kinds = r.integers(0, 100, k)
+        title = b" ".join(words[int(i)].capitalize() for i in r.integers(0, len(words), int(r.integers(1, 4))))
+        head = (b"  <page>\n    <title>" + title + b"</title>\n    <id>" + str(page * 7 + 3).encode() + b"</id>\n"
+                b"    <revision>\n      <id>" + str(15898000 + page * 11).encode() + b"</id>\n      <timestamp>2006-0"
+                + str(1 + page % 9).encode() + b"-1" + str(page % 10).encode() + b"T0" + str(page % 10).encode()
+                + b":42:" + str(10 + page % 50).encode() + b"Z</timestamp>\n      <contributor>\n        <username>"
+                + words[int(idx[0])].capitalize() + b"</username>\n        <id>" + str(int(kinds[0]) * 131).encode()
+                + b"</id>\n      </contributor>\n      <text xml:space=\"preserve\">")
+        body = bytearray()
+        col = 0
+        for w, kind in zip(idx, kinds):
+            word = words[int(w)]
+            if kind < 4:
+                body += b"[[" + word + b"]]"
+            elif kind < 6:
+                body += b"[[" + word + b"|" + words[int(w) // 2] + b"]]"
+            elif kind < 7:
+                body += b"''" + word + b"''"
+            elif kind < 8:
+                body += b"\n\n== " + word.capitalize() + b" ==\n"
+                col = 0
+                continue
+            elif kind < 9:
+                body += b"{{" + word + b"|" + str(int(w)).encode() + b"}}"
+            elif kind < 10:
+                body += b"&quot;" + word + b"&quot;"
+            elif kind < 11:
+                body += b"\n* " + word
+                col = 0
+            elif kind < 13:
+                body += word + b","
+            elif kind < 16:
+                body += word.capitalize() if col == 0 else word + b"."
+            else:
+                body += word
+            col += len(word) + 1
+            if col > 200 and kind % 5 == 0:
+                body += b"\n\n"
+                col = 0
+            else:
+                body += b" "
+        tail = b"</text>\n    </revision>\n  </page>\n"
+        piece = head + bytes(body) + tail
+        out.append(piece)
+        size += len(piece)
+    data = b"<mediawiki xml:lang=\"en\">\n" + b"".join(out)
+    return data[:n]
+
+
 def corpus_small():
     """name -> (raw, level) : fast cases for both CPU and GPU suites."""
     cases = {
