@@ -121,13 +121,18 @@ void mi355x_bz2_destroy( mi355x_bz2_ctx* ctx );
 const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
 
 /* Make the compressed file (or any byte range of it; bit offsets below are relative to `bytes[0]`) resident in HBM.
- * Both forms COPY into ctx-owned memory: the kernels read the stream as big-endian 32-bit words (byte-swapped once,
- * while it is copied) with 16-byte loads and no bounds checks, so the copy is word-swapped and zero padded by >= 256
- * bytes.  _host copies H2D (pageable or page-locked host memory), _device copies D2D from a device pointer that is
- * only read during the call (4-byte aligned; size need not be padded).  The caller's buffer may be freed afterwards;
- * the copy costs one extra `size` bytes of HBM.
+ * All forms COPY into ctx-owned memory, in file byte order: the kernels read the stream with 16-byte loads and no bounds
+ * checks, so the copy is zero padded by >= 256 bytes (they swap each 32-bit word as they load it; there is no swapped
+ * copy and no swap pass).  _host copies H2D (pageable or page-locked host memory) and waits; _device copies D2D from a
+ * device pointer that is only read during the call (size need not be padded).  The caller's buffer may be freed
+ * afterwards; the copy costs `size` bytes of HBM.
+ * _host_async only QUEUES the H2D copy on the context's stream (in 64-MiB pieces) and returns: the next
+ * decode_batch[_begin] on this context is ordered behind it, so the transfer overlaps with whatever other contexts are
+ * running.  `bytes` should be page-locked (hipHostMalloc / hipHostRegister) and must stay valid until that batch's
+ * decode_batch_end has returned.
  * Replaces the BitReader/SharedFileReader clone + pread of BZ2BlockFetcher.hpp:89-90. */
 int mi355x_bz2_set_input_host( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
+int mi355x_bz2_set_input_host_async( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
 int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, uint64_t size );
 /* Several contexts over ONE resident copy of the input (the reader keeps two contexts to overlap consecutive batches):
  * `ctx` decodes from the bytes `from` made resident.  Nothing is copied; `from` must outlive `ctx`'s use of them and

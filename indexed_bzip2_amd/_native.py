@@ -91,6 +91,7 @@ SYMBOLS = [
     ("mi355x_bz2_destroy", None, [_vp]),
     ("mi355x_bz2_last_error", ctypes.c_char_p, [_vp]),
     ("mi355x_bz2_set_input_host", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64]),
+    ("mi355x_bz2_set_input_host_async", ctypes.c_int, [_vp, ctypes.c_void_p, ctypes.c_uint64]),
     ("mi355x_bz2_set_input_device", ctypes.c_int, [_vp, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_decode_batch", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.POINTER(BlockResult), _u64p]),
     ("mi355x_bz2_decode_batch_begin", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32]),
@@ -206,6 +207,13 @@ class Decoder:
     def set_input(self, data: bytes):
         self._check(lib().mi355x_bz2_set_input_host(self._h, data, len(data)))
 
+    def set_input_host_async(self, ptr: int, size: int, keepalive=None):
+        """Queue the H2D copy of `size` bytes at host address `ptr` (page-locked memory) on the decoder's stream and
+        return: the next begin_batch / decode_batch is ordered behind it.  The memory must stay valid until that batch
+        has ended."""
+        self._input_ref = keepalive
+        self._check(lib().mi355x_bz2_set_input_host_async(self._h, ptr, size))
+
     def set_input_device(self, ptr: int, size: int, keepalive=None):
         self._input_ref = keepalive
         self._check(lib().mi355x_bz2_set_input_device(self._h, ptr, size))
@@ -295,7 +303,10 @@ class Decoder:
         return t.as_dict()
 
     def debug_stage(self, index: int, stage: int) -> bytes:
-        n = self.last_results[index]["bwt_length"] * (4 if stage == 1 else 1)
+        if stage >= 3:      # k_hscan hand-off: 3 = group starts (u32 each), 4 = ScanMeta, 5 = selectors
+            n = {3: 18048 * 4, 4: 32, 5: 32768}[stage]
+        else:
+            n = self.last_results[index]["bwt_length"] * (4 if stage == 1 else 1)
         buf = ctypes.create_string_buffer(max(1, n))
         self._check(lib().mi355x_bz2_debug_copy_stage(self._h, index, stage, buf, n))
         return buf.raw[:n]

@@ -403,11 +403,14 @@ mi355x_bz2_last_error( const mi355x_bz2_ctx* c )
     return c != nullptr ? c->lastError.c_str() : "null context";
 }
 
-int
-mi355x_bz2_set_input_host( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t size )
+namespace
 {
-    if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
-    const std::scoped_lock lock( c->mutex );
+/** Reserve the ctx-owned input copy and queue `size` bytes into it (host or device source) on the ctx stream, zero padded;
+ * no wait.  Copies of more than 64 MiB from the host go in pieces, so that the first kernels of another context's batch
+ * are not queued behind one long transfer. */
+int
+queueInput( mi355x_bz2_ctx* c, const void* bytes, uint64_t size, hipMemcpyKind kind )
+{
     HIP_TRY( c, hipSetDevice( c->device ) );
     const uint64_t padded = ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256;
     if ( padded > c->dInOwnedCapacity ) {
@@ -419,44 +422,50 @@ mi355x_bz2_set_input_host( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t siz
         c->dInOwnedCapacity = padded;
     }
     HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0, padded - ( size & ~uint64_t( 255 ) ), c->stream ) );
-    if ( size > 0 ) {
-        HIP_TRY( c, hipMemcpyAsync( c->dInOwned, bytes, size, hipMemcpyHostToDevice, c->stream ) );
+    constexpr uint64_t PIECE = uint64_t( 64 ) << 20;
+    for ( uint64_t at = 0; at < size; at += PIECE ) {
+        HIP_TRY( c, hipMemcpyAsync( c->dInOwned + at, static_cast<const uint8_t*>( bytes ) + at, std::min( PIECE, size - at ),
+                                    kind, c->stream ) );
     }
-    hipLaunchKernelGGL( k_bswap32, dim3( 2048 ), dim3( 256 ), 0, c->stream,
-                        reinterpret_cast<uint32_t*>( c->dInOwned ), padded / 4 );
-    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     c->dIn = c->dInOwned;
     c->inSize = size;
     return MI355X_BZ2_OK;
+}
+}  // namespace
+
+int
+mi355x_bz2_set_input_host( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t size )
+{
+    if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    const int rc = queueInput( c, bytes, size, hipMemcpyHostToDevice );
+    if ( rc != MI355X_BZ2_OK ) return rc;
+    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_set_input_host_async( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t size )
+{
+    if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "set_input_host_async: a batch is in flight";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    return queueInput( c, bytes, size, hipMemcpyHostToDevice );
 }
 
 int
 mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_t size )
 {
     if ( c == nullptr || ( deviceBytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
-    if ( ( reinterpret_cast<uintptr_t>( deviceBytes ) & 3u ) != 0 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex );
     /* The kernels read whole 16-byte windows without bounds checks, so the bytes are copied (device to device, once)
      * into ctx-owned memory that is zero padded past the end. */
-    HIP_TRY( c, hipSetDevice( c->device ) );
-    const uint64_t padded = ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256;
-    if ( padded > c->dInOwnedCapacity ) {
-        HIP_TRY( c, hipStreamSynchronize( c->stream ) );
-        (void)hipFree( c->dInOwned );
-        c->dInOwned = nullptr;
-        c->dInOwnedCapacity = 0;
-        HIP_TRY( c, hipMalloc( &c->dInOwned, padded ) );
-        c->dInOwnedCapacity = padded;
-    }
-    HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0, padded - ( size & ~uint64_t( 255 ) ), c->stream ) );
-    if ( size > 0 ) {
-        HIP_TRY( c, hipMemcpyAsync( c->dInOwned, deviceBytes, size, hipMemcpyDeviceToDevice, c->stream ) );
-    }
-    hipLaunchKernelGGL( k_bswap32, dim3( 2048 ), dim3( 256 ), 0, c->stream,
-                        reinterpret_cast<uint32_t*>( c->dInOwned ), padded / 4 );
+    const int rc = queueInput( c, deviceBytes, size, hipMemcpyDeviceToDevice );
+    if ( rc != MI355X_BZ2_OK ) return rc;
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
-    c->dIn = c->dInOwned;
-    c->inSize = size;
     return MI355X_BZ2_OK;
 }
 
@@ -615,6 +624,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * "window" = k_huff (one serial chain per block) */
     const char* hm = std::getenv( "MI355X_BZ2_HUFF" );
     const bool useScan = !( hm != nullptr && std::strcmp( hm, "window" ) == 0 );
+    const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: wavefronts per block in k_hscan (1, 2, 4, 8) */
+    const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;
+    const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
+    const uint32_t scanTune = st != nullptr ? (uint32_t)std::atoi( st ) : 0u;
     const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
     const uint32_t huffCapExpensive = hce != nullptr && std::atoi( hce ) > 0 ? (uint32_t)std::atoi( hce ) : 0xFFFFFFFFu;
     for ( int launch = 0; launch < nGroups; ++launch ) {
@@ -646,9 +659,23 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             ScanMeta* const smeta = c->dSmeta + first;
             HuffTables* const htab = c->dHtab + first;
             uint32_t* const gpos = c->dGpos + (size_t)first * GPOS_STRIDE;
-            TIMED_LAUNCH( c, g, q, 12, k_hscan, dim3( m ), dim3( 64 ), 0, q,
-                          reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, smeta,
-                          sel, stb, htab, gpos, m, order );
+            /* wavefronts per block: one when the batch fills the GPU by itself, four or eight (speculative builds of
+             * the next groups, see bz2_hscan.hip.h) when few blocks have to be through quickly */
+            const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves : ( n <= 64 ? 8u : ( n <= 1280 ? 4u : 1u ) );
+            const auto* const inWords = reinterpret_cast<const uint32_t*>( c->dIn );
+            if ( scanWaves >= 8 ) {
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            } else if ( scanWaves >= 4 ) {
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            } else if ( scanWaves >= 2 ) {
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            } else {
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( m ), dim3( 64 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            }
             TIMED_LAUNCH( c, g, q, 13, k_hsym, dim3( ( MAX_SCAN_GROUPS + SYM_THREADS - 1 ) / SYM_THREADS, m ), dim3( SYM_THREADS ),
                           0, q, reinterpret_cast<const uint32_t*>( c->dIn ), meta, hmeta, smeta, sel, htab, gpos, sym );
         } else {
@@ -889,6 +916,9 @@ mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* c, uint32_t index, int stage, void*
     case 0: src = c->dL + (size_t)index * L_STRIDE; bytes = N; break;
     case 1: src = c->dTab + (size_t)index * TAB_STRIDE; bytes = N * 4; break;
     case 2: src = c->dR + (size_t)index * L_STRIDE; bytes = N; break;
+    case 3: src = c->dGpos + (size_t)index * GPOS_STRIDE; bytes = (uint64_t)GPOS_STRIDE * 4; break;   /* group starts (k_hscan) */
+    case 4: src = c->dSmeta + index; bytes = sizeof( ScanMeta ); break;
+    case 5: src = c->dSel + (size_t)index * SEL_STRIDE; bytes = SEL_STRIDE; break;
     default: return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
     if ( bytes > capacity ) bytes = capacity;

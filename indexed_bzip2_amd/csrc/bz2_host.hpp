@@ -1,12 +1,18 @@
 /**
- * bz2_host.hpp -- host-side scheduler pieces kept from the reference's architecture, restated
- * batch-oriented for a GPU backend.  Product code (never touches oracle/).
+ * bz2_host.hpp -- host-side pieces of the reader, batch-oriented for a GPU backend.  Product code (never touches oracle/).
+ * The BEHAVIOUR of the reference's scheduler classes is kept where callers can observe it and is pinned
+ * by answers recorded from the reference's own classes (tests/golden/host_vectors.txt, replayed by
+ * tests/native/host_known_answers.cpp); the data structures are this design's own:
  *
- *   BlockMap            <- rapidgzip::BlockMap                       src/core/BlockMap.hpp:26-295
- *   LruCache            <- rapidgzip::Cache + LeastRecentlyUsed      src/core/Cache.hpp:47-296
- *   FetchNextAdaptive   <- FetchingStrategy::FetchNextAdaptive       src/core/Prefetcher.hpp:82-217
- *   BlockFinder         <- rapidgzip::BlockFinder + StreamedResults  src/core/BlockFinder.hpp:36-219,
- *                                                                    src/core/StreamedResults.hpp:26-156
+ *   BlockIndex            two flat arrays (compressed bit offset, decoded byte offset) + the size of the open last block;
+ *                         what rapidgzip::BlockMap answers                 src/core/BlockMap.hpp:26-295
+ *   SequentialityTracker  the last few block numbers that were asked for -> ONE range [first, first + count) worth
+ *                         decoding ahead; same amounts as FetchNextAdaptive  src/core/Prefetcher.hpp:82-217
+ *   RunCache              decoded batches ("runs" of consecutive blocks that share one host buffer), budgeted in blocks,
+ *                         least recently used run out first; the role of Cache + the prefetch cache,
+ *                                                                          src/core/Cache.hpp:117-296
+ *   BlockFinder           producer of block offsets, chunk-wise magic scan   src/core/BlockFinder.hpp:36-219,
+ *                                                                          src/core/StreamedResults.hpp:26-156
  */
 #pragma once
 
@@ -18,13 +24,12 @@
 #include <deque>
 #include <functional>
 #include <limits>
-#include <list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <thread>
-#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -35,417 +40,434 @@ void
 scanMagicRange( const uint8_t* bytes, uint64_t size, uint64_t magic48, uint64_t begin, uint64_t end,
                 std::vector<uint64_t>& found );
 
-/* ------------------------------------------------------------------------------------------------ BlockMap */
-class BlockMap
+/* ------------------------------------------------------------------------------------------------ block index */
+/**
+ * Where every block starts, compressed (bits) and decoded (bytes).  End-of-stream blocks are entries of decoded size 0;
+ * seal() adds the end-of-file entry, after which the index is what IndexedBzip2File.block_offsets() returns.
+ * Entries only ever grow at the end, so the two columns are plain sorted arrays and every look-up is a binary search.
+ */
+class BlockIndex
 {
 public:
-    struct BlockInfo
-    {
-        [[nodiscard]] bool
-        contains( size_t dataOffset ) const
-        {
-            return ( decodedOffsetInBytes <= dataOffset ) && ( dataOffset < decodedOffsetInBytes + decodedSizeInBytes );
-        }
+    using Pairs = std::vector<std::pair<uint64_t, uint64_t> >;
 
-        size_t blockIndex{ 0 };
-        size_t encodedOffsetInBits{ 0 };
-        size_t encodedSizeInBits{ 0 };
-        size_t decodedOffsetInBytes{ 0 };
-        size_t decodedSizeInBytes{ 0 };
+    struct Span
+    {
+        size_t   ordinal{ 0 };      /* position in the index, end-of-stream entries included */
+        uint64_t bits{ 0 }, bitLength{ 0 };
+        uint64_t bytes{ 0 }, byteLength{ 0 };
+
+        [[nodiscard]] bool
+        covers( uint64_t byteOffset ) const
+        {
+            return ( byteOffset >= bytes ) && ( byteOffset - bytes < byteLength );
+        }
     };
 
-    using Offsets = std::vector<std::pair<size_t, size_t> >;
-
-    /** BlockMap::push, BlockMap.hpp:69-119 */
-    size_t
-    push( size_t encodedBlockOffset, size_t encodedSize, size_t decodedSize )
+    /** A block decoded for the first time, in file order.  Returns where its bytes start.  A block that is already known
+     * (decoded again after a seek) is accepted if its size agrees and is otherwise an error, like any offset that does not
+     * continue the index. */
+    uint64_t
+    append( uint64_t bits, uint64_t bitLength, uint64_t byteLength )
     {
         const std::scoped_lock lock( m_mutex );
-        if ( m_finalized ) {
-            throw std::invalid_argument( "May not insert into finalized block map!" );
+        if ( m_sealed ) {
+            throw std::invalid_argument( "the block index is complete: nothing can be appended" );
         }
-        std::optional<size_t> decodedOffset;
-        if ( m_offsets.empty() ) {
-            decodedOffset = 0;
-        } else if ( encodedBlockOffset > m_offsets.back().first ) {
-            decodedOffset = m_offsets.back().second + m_lastDecodedSize;
+        if ( m_bits.empty() || ( bits > m_bits.back() ) ) {
+            const uint64_t at = m_bits.empty() ? 0 : m_bytes.back() + m_openBytes;
+            m_bits.push_back( bits );
+            m_bytes.push_back( at );
+            m_openBits = bitLength;
+            m_openBytes = byteLength;
+            m_emptyBlocks += byteLength == 0 ? 1 : 0;
+            return at;
         }
-        if ( decodedOffset ) {
-            m_offsets.emplace_back( encodedBlockOffset, *decodedOffset );
-            if ( decodedSize == 0 ) {
-                m_eosBlocks.push_back( encodedBlockOffset );
-            }
-            m_lastDecodedSize = decodedSize;
-            m_lastEncodedSize = encodedSize;
-            return *decodedOffset;
+        const auto known = std::lower_bound( m_bits.begin(), m_bits.end(), bits );
+        const auto i = static_cast<size_t>( known - m_bits.begin() );
+        if ( *known != bits ) {
+            throw std::invalid_argument( "block offsets have to arrive in increasing order" );
         }
-        const auto match = std::lower_bound( m_offsets.begin(), m_offsets.end(),
-                                             std::make_pair( encodedBlockOffset, size_t( 0 ) ),
-                                             [] ( const auto& a, const auto& b ) { return a.first < b.first; } );
-        if ( ( match == m_offsets.end() ) || ( match->first != encodedBlockOffset ) ) {
-            throw std::invalid_argument( "Inserted block offsets should be strictly increasing!" );
+        if ( i + 1 == m_bits.size() ) {
+            throw std::logic_error( "the open last block cannot be appended twice" );
         }
-        if ( std::next( match ) == m_offsets.end() ) {
-            throw std::logic_error( "In this case, the new block should already have been appended above!" );
+        if ( m_bytes[i + 1] - m_bytes[i] != byteLength ) {
+            throw std::invalid_argument( "a known block came back with another decoded size" );
         }
-        if ( std::next( match )->second - match->second != decodedSize ) {
-            throw std::invalid_argument( "Got duplicate block offset with inconsistent size!" );
-        }
-        return match->second;
+        return m_bytes[i];
     }
 
-    /** BlockMap::findDataOffset, BlockMap.hpp:125-144: last block whose decoded offset is <= dataOffset */
-    [[nodiscard]] BlockInfo
-    findDataOffset( size_t dataOffset ) const
+    /** The last entry that starts at or before byteOffset (among entries with equal starts -- an end-of-stream block and
+     * the block behind it -- the later one).  An all-zero Span if there is none. */
+    [[nodiscard]] Span
+    locate( uint64_t byteOffset ) const
     {
         const std::scoped_lock lock( m_mutex );
-        /* entries have non-decreasing .second; find the LAST entry with second <= dataOffset */
-        auto it = std::upper_bound( m_offsets.begin(), m_offsets.end(), dataOffset,
-                                    [] ( size_t value, const auto& entry ) { return value < entry.second; } );
-        if ( it == m_offsets.begin() ) {
+        const auto behind = std::upper_bound( m_bytes.begin(), m_bytes.end(), byteOffset );
+        if ( behind == m_bytes.begin() ) {
             return {};
         }
-        --it;
-        return get( (size_t)std::distance( m_offsets.begin(), it ) );
+        return spanAt( static_cast<size_t>( behind - m_bytes.begin() ) - 1 );
     }
 
+    /** Decoded bytes covered so far: the end of the last block. */
+    [[nodiscard]] uint64_t
+    frontier() const
+    {
+        const std::scoped_lock lock( m_mutex );
+        return m_bytes.empty() ? 0 : m_bytes.back() + m_openBytes;
+    }
+
+    /** Data blocks, i.e. entries that are neither end-of-stream blocks nor the end-of-file entry. */
     [[nodiscard]] size_t
-    dataBlockCount() const
+    dataBlocks() const
     {
         const std::scoped_lock lock( m_mutex );
-        return m_offsets.size() - m_eosBlocks.size();
+        return m_bits.size() - m_emptyBlocks;
     }
 
-    /** BlockMap::finalize, BlockMap.hpp:171-197 */
+    /** No more blocks: close the last one with the end-of-file entry {bits behind it, total decoded size}. */
     void
-    finalize()
+    seal()
     {
         const std::scoped_lock lock( m_mutex );
-        if ( m_finalized ) {
+        if ( m_sealed ) {
             return;
         }
-        if ( m_offsets.empty() ) {
-            m_offsets.emplace_back( m_lastEncodedSize, m_lastDecodedSize );
-        } else if ( ( m_lastEncodedSize != 0 ) || ( m_lastDecodedSize != 0 ) ) {
-            const auto [lastEncoded, lastDecoded] = m_offsets.back();
-            m_offsets.emplace_back( lastEncoded + m_lastEncodedSize, lastDecoded + m_lastDecodedSize );
+        if ( m_bits.empty() ) {
+            m_bits.push_back( m_openBits );
+            m_bytes.push_back( m_openBytes );
+        } else if ( ( m_openBits | m_openBytes ) != 0 ) {
+            m_bits.push_back( m_bits.back() + m_openBits );
+            m_bytes.push_back( m_bytes.back() + m_openBytes );
         }
-        m_lastEncodedSize = 0;
-        m_lastDecodedSize = 0;
-        m_finalized = true;
+        m_openBits = m_openBytes = 0;
+        m_sealed = true;
     }
 
     [[nodiscard]] bool
-    finalized() const
+    sealed() const
     {
         const std::scoped_lock lock( m_mutex );
-        return m_finalized;
+        return m_sealed;
     }
 
-    /** BlockMap::setBlockOffsets, BlockMap.hpp:207-230 */
+    /** Import of a complete index (sorted by bit offset): entries followed by an equal decoded offset are end-of-stream
+     * blocks, the last entry is the end of the file. */
     void
-    setBlockOffsets( const std::map<size_t, size_t>& blockOffsets )
+    assign( const Pairs& sortedPairs )
     {
         const std::scoped_lock lock( m_mutex );
-        m_offsets.assign( blockOffsets.begin(), blockOffsets.end() );
-        m_lastEncodedSize = 0;
-        m_lastDecodedSize = 0;
-        m_eosBlocks.clear();
-        for ( size_t i = 0; i + 1 < m_offsets.size(); ++i ) {
-            if ( m_offsets[i].second == m_offsets[i + 1].second ) {
-                m_eosBlocks.push_back( m_offsets[i].first );
-            }
+        m_bits.clear();
+        m_bytes.clear();
+        m_bits.reserve( sortedPairs.size() );
+        m_bytes.reserve( sortedPairs.size() );
+        for ( const auto& [bits, bytes] : sortedPairs ) {
+            m_bits.push_back( bits );
+            m_bytes.push_back( bytes );
         }
-        m_eosBlocks.push_back( m_offsets.back().first );
-        m_finalized = true;
+        m_emptyBlocks = m_bytes.empty() ? 0 : 1;
+        for ( size_t i = 0; i + 1 < m_bytes.size(); ++i ) {
+            m_emptyBlocks += m_bytes[i] == m_bytes[i + 1] ? 1 : 0;
+        }
+        m_openBits = m_openBytes = 0;
+        m_sealed = true;
     }
 
-    [[nodiscard]] std::map<size_t, size_t>
-    blockOffsets() const
+    [[nodiscard]] Pairs
+    snapshot() const
     {
         const std::scoped_lock lock( m_mutex );
-        return { m_offsets.begin(), m_offsets.end() };
+        Pairs result( m_bits.size() );
+        for ( size_t i = 0; i < m_bits.size(); ++i ) {
+            result[i] = { m_bits[i], m_bytes[i] };
+        }
+        return result;
     }
 
-    [[nodiscard]] std::pair<size_t, size_t>
-    back() const
+    [[nodiscard]] std::pair<uint64_t, uint64_t>
+    last() const
     {
         const std::scoped_lock lock( m_mutex );
-        if ( m_offsets.empty() ) {
-            throw std::out_of_range( "Can not return last element of empty block map!" );
+        if ( m_bits.empty() ) {
+            throw std::out_of_range( "the block index is empty" );
         }
-        return m_offsets.back();
+        return { m_bits.back(), m_bytes.back() };
     }
 
     [[nodiscard]] bool
     empty() const
     {
         const std::scoped_lock lock( m_mutex );
-        return m_offsets.empty();
+        return m_bits.empty();
     }
 
 private:
-    [[nodiscard]] BlockInfo
-    get( size_t i ) const
+    [[nodiscard]] Span
+    spanAt( size_t i ) const
     {
-        BlockInfo result;
-        result.encodedOffsetInBits = m_offsets[i].first;
-        result.decodedOffsetInBytes = m_offsets[i].second;
-        result.blockIndex = i;
-        if ( i + 1 == m_offsets.size() ) {
-            result.decodedSizeInBytes = m_lastDecodedSize;
-            result.encodedSizeInBits = m_lastEncodedSize;
-        } else {
-            if ( m_offsets[i + 1].second < m_offsets[i].second ) {
-                throw std::logic_error( "Data offsets are not monotonically increasing!" );
+        Span span;
+        span.ordinal = i;
+        span.bits = m_bits[i];
+        span.bytes = m_bytes[i];
+        if ( i + 1 < m_bits.size() ) {
+            if ( m_bytes[i + 1] < m_bytes[i] ) {
+                throw std::logic_error( "decoded offsets of the block index decrease" );
             }
-            result.decodedSizeInBytes = m_offsets[i + 1].second - m_offsets[i].second;
-            result.encodedSizeInBits = m_offsets[i + 1].first - m_offsets[i].first;
+            span.bitLength = m_bits[i + 1] - m_bits[i];
+            span.byteLength = m_bytes[i + 1] - m_bytes[i];
+        } else {
+            span.bitLength = m_openBits;
+            span.byteLength = m_openBytes;
+        }
+        return span;
+    }
+
+    mutable std::mutex m_mutex;
+    std::vector<uint64_t> m_bits, m_bytes;          /* sorted; m_bytes non-decreasing */
+    uint64_t m_openBits{ 0 }, m_openBytes{ 0 };     /* size of the last block while the index is still growing */
+    size_t m_emptyBlocks{ 0 };
+    bool m_sealed{ false };
+};
+
+/* ------------------------------------------------------------------------------------------------ access pattern */
+/**
+ * Remembers the last few block numbers a reader asked for and says how far ahead decoding is worth it: everything the
+ * caller allows while the accesses came in order, nothing for random accesses, and limit^(streak / depth) in between, so
+ * that one stray seek does not stop a sequential reader and a few ordered accesses restart it.  The answer is one range.
+ */
+class SequentialityTracker
+{
+public:
+    struct Range
+    {
+        size_t first{ 0 }, count{ 0 };
+    };
+
+    explicit
+    SequentialityTracker( size_t depth = 3 ) :
+        m_depth( std::max<size_t>( depth, 1 ) )
+    {
+        m_recent.reserve( m_depth + 1 );
+    }
+
+    /** A block was asked for.  Asking for the same block again (small reads inside one block) changes nothing. */
+    void
+    note( size_t block )
+    {
+        if ( !m_recent.empty() && ( m_recent.front() == block ) ) {
+            return;
+        }
+        m_recent.insert( m_recent.begin(), block );
+        if ( m_recent.size() > m_depth ) {
+            m_recent.pop_back();
+        }
+    }
+
+    /** True while every remembered access followed its predecessor (also with fewer than two accesses). */
+    [[nodiscard]] bool
+    inOrder() const noexcept
+    {
+        return steps() + 1 >= m_recent.size();
+    }
+
+    [[nodiscard]] Range
+    ahead( size_t limit ) const
+    {
+        const size_t known = m_recent.size();
+        if ( ( known == 0 ) || ( limit == 0 ) ) {
+            return {};
+        }
+        const size_t next = m_recent.front() + 1;
+        if ( known == 1 ) {
+            return { next, limit };   /* a fresh reader: one miss, then everything in parallel */
+        }
+        if ( steps() == 0 ) {
+            return {};                /* nothing but jumps */
+        }
+        /* how much of the memory is one unbroken run up to the newest access */
+        size_t streak = 0;
+        while ( ( streak + 1 < known ) && ( m_recent[streak] == m_recent[streak + 1] + 1 ) ) {
+            ++streak;
+        }
+        const double confidence = streak == 0 ? 0.0 : static_cast<double>( streak + 1 ) / static_cast<double>( known );
+        const double amount = std::round( std::exp2( confidence * std::log2( static_cast<double>( limit ) ) ) );
+        return { next, static_cast<size_t>( std::max( 0.0, amount ) ) };
+    }
+
+private:
+    /** Number of remembered accesses that directly followed the one before them. */
+    [[nodiscard]] size_t
+    steps() const noexcept
+    {
+        size_t result = 0;
+        for ( size_t i = 0; i + 1 < m_recent.size(); ++i ) {
+            result += m_recent[i] == m_recent[i + 1] + 1 ? 1 : 0;
         }
         return result;
     }
 
-    mutable std::mutex m_mutex;
-    Offsets m_offsets;
-    std::vector<size_t> m_eosBlocks;
-    bool m_finalized{ false };
-    size_t m_lastEncodedSize{ 0 };
-    size_t m_lastDecodedSize{ 0 };
+    size_t m_depth;
+    std::vector<size_t> m_recent;   /* newest first */
 };
 
-/* ------------------------------------------------------------------------------------------------ LRU cache */
-template<typename Key, typename Value>
-class LruCache
+/* ------------------------------------------------------------------------------------------------ decoded runs */
+/**
+ * Decoded batches by the number of their first block.  `Run` provides first() and count() (consecutive block numbers
+ * [first, first + count)).  The budget is in blocks; when it is exceeded the least recently used runs go, never the one
+ * that was just put in.  Statistics in the spirit of Cache::Statistics (src/core/Cache.hpp:120-140): a run that leaves
+ * without ever having been asked for counts as unused; replacing a run by a new one for the same blocks does not.
+ */
+template<typename Run>
+class RunCache
 {
 public:
     struct Statistics
     {
-        size_t hits{ 0 };
-        size_t misses{ 0 };
-        size_t unusedEntries{ 0 };
-        size_t capacity{ 0 };
-        size_t maxSize{ 0 };
+        size_t hits{ 0 }, misses{ 0 }, unusedRuns{ 0 }, evictions{ 0 }, maxBlocks{ 0 };
     };
 
     explicit
-    LruCache( size_t capacity ) :
-        m_capacity( capacity )
+    RunCache( size_t blockBudget ) :
+        m_budget( blockBudget )
     {}
 
-    [[nodiscard]] std::optional<Value>
-    get( const Key& key )
+    /** The run that holds `block`, marked as used now; nullptr if none does. */
+    [[nodiscard]] std::shared_ptr<const Run>
+    find( size_t block )
     {
-        const auto match = m_entries.find( key );
-        if ( match == m_entries.end() ) {
+        const auto entry = locate( block );
+        if ( entry == m_runs.end() ) {
             ++m_statistics.misses;
-            return std::nullopt;
+            return nullptr;
         }
         ++m_statistics.hits;
-        ++match->second.accesses;
-        touchEntry( match );
-        return match->second.value;
-    }
-
-    void
-    insert( Key key, Value value )
-    {
-        if ( m_capacity == 0 ) {
-            return;
-        }
-        auto match = m_entries.find( key );
-        if ( match == m_entries.end() ) {
-            shrinkTo( m_capacity - 1 );
-            m_order.push_back( key );
-            Entry entry{ std::move( value ), std::prev( m_order.end() ), 0 };
-            m_entries.emplace( std::move( key ), std::move( entry ) );
-            m_statistics.maxSize = std::max( m_statistics.maxSize, m_entries.size() );
-        } else {
-            match->second.value = std::move( value );
-            touchEntry( match );
-        }
-    }
-
-    void
-    touch( const Key& key )
-    {
-        const auto match = m_entries.find( key );
-        if ( match != m_entries.end() ) {
-            touchEntry( match );
-        }
+        ++entry->second.uses;
+        entry->second.lastUse = ++m_clock;
+        return entry->second.run;
     }
 
     [[nodiscard]] bool
-    test( const Key& key ) const
+    covers( size_t block ) const
     {
-        return m_entries.find( key ) != m_entries.end();
+        return const_cast<RunCache*>( this )->locate( block ) != m_runs.end();
+    }
+
+    /** The first block at or behind `block` that no run holds. */
+    [[nodiscard]] size_t
+    firstGap( size_t block ) const
+    {
+        for ( auto entry = const_cast<RunCache*>( this )->locate( block ); entry != m_runs.end();
+              entry = const_cast<RunCache*>( this )->locate( block ) ) {
+            block = entry->first + entry->second.run->count();
+        }
+        return block;
+    }
+
+    /** How many of the blocks [first, end) some run holds. */
+    [[nodiscard]] size_t
+    blocksWithin( size_t first, size_t end ) const
+    {
+        size_t result = 0;
+        for ( const auto& [runFirst, entry] : m_runs ) {
+            const size_t lo = std::max( first, runFirst ), hi = std::min( end, runFirst + entry.run->count() );
+            result += hi > lo ? hi - lo : 0;
+        }
+        return result;
+    }
+
+    void
+    insert( std::shared_ptr<const Run> run )
+    {
+        if ( !run || ( run->count() == 0 ) ) {
+            return;
+        }
+        const size_t first = run->first();
+        if ( const auto same = m_runs.find( first ); same != m_runs.end() ) {
+            /* the same blocks decoded again: not an eviction, and its use count carries over */
+            m_blocks -= same->second.run->count();
+            m_blocks += run->count();
+            same->second.run = std::move( run );
+            same->second.lastUse = ++m_clock;
+        } else {
+            m_blocks += run->count();
+            m_runs.emplace( first, Entry{ std::move( run ), ++m_clock, 0 } );
+        }
+        while ( ( m_blocks > m_budget ) && ( m_runs.size() > 1 ) ) {
+            auto oldest = m_runs.end();
+            for ( auto entry = m_runs.begin(); entry != m_runs.end(); ++entry ) {
+                if ( ( entry->first != first ) && ( ( oldest == m_runs.end() ) || ( entry->second.lastUse < oldest->second.lastUse ) ) ) {
+                    oldest = entry;
+                }
+            }
+            if ( oldest == m_runs.end() ) {
+                break;
+            }
+            drop( oldest );
+        }
+        m_statistics.maxBlocks = std::max( m_statistics.maxBlocks, m_blocks );
+    }
+
+    /** A reader that goes through the file in order never comes back: forget every run that ends at or before `block`. */
+    void
+    dropBefore( size_t block )
+    {
+        for ( auto entry = m_runs.begin(); entry != m_runs.end(); ) {
+            if ( entry->first + entry->second.run->count() <= block ) {
+                entry = drop( entry );
+            } else {
+                ++entry;
+            }
+        }
     }
 
     void
     clear()
     {
-        m_entries.clear();
-        m_order.clear();
+        m_runs.clear();
+        m_blocks = 0;
     }
 
-    void
-    evict( const Key& key )
-    {
-        const auto match = m_entries.find( key );
-        if ( match != m_entries.end() ) {
-            m_order.erase( match->second.position );
-            m_entries.erase( match );
-        }
-    }
-
-    /** Key that would be evicted by the n-th hypothetical insertion (Cache::nextNthEviction, Cache.hpp:217-224). */
-    [[nodiscard]] std::optional<Key>
-    nextNthEviction( size_t countToBeInserted ) const
-    {
-        const auto freeCapacity = m_capacity - m_entries.size();
-        if ( countToBeInserted <= freeCapacity ) {
-            return std::nullopt;
-        }
-        const auto n = countToBeInserted - freeCapacity;
-        if ( ( n == 0 ) || ( n > m_order.size() ) ) {
-            return std::nullopt;
-        }
-        return *std::next( m_order.begin(), (std::ptrdiff_t)( n - 1 ) );
-    }
-
-    void
-    shrinkTo( size_t newSize )
-    {
-        while ( m_entries.size() > newSize ) {
-            const auto key = m_order.front();
-            const auto match = m_entries.find( key );
-            if ( match->second.accesses == 0 ) {
-                ++m_statistics.unusedEntries;
-            }
-            m_entries.erase( match );
-            m_order.pop_front();
-        }
-    }
-
-    [[nodiscard]] Statistics
-    statistics() const
-    {
-        auto result = m_statistics;
-        result.capacity = m_capacity;
-        return result;
-    }
-
-    [[nodiscard]] size_t
-    capacity() const
-    {
-        return m_capacity;
-    }
-
-    [[nodiscard]] size_t
-    size() const
-    {
-        return m_entries.size();
-    }
+    [[nodiscard]] size_t blocks() const { return m_blocks; }
+    [[nodiscard]] size_t runs() const { return m_runs.size(); }
+    [[nodiscard]] size_t budget() const { return m_budget; }
+    [[nodiscard]] Statistics statistics() const { return m_statistics; }
 
 private:
     struct Entry
     {
-        Value value;
-        typename std::list<Key>::iterator position;
-        size_t accesses{ 0 };
+        std::shared_ptr<const Run> run;
+        uint64_t lastUse{ 0 };
+        size_t uses{ 0 };
     };
 
-    void
-    touchEntry( typename std::unordered_map<Key, Entry>::iterator match )
+    using Runs = std::map<size_t, Entry>;
+
+    typename Runs::iterator
+    locate( size_t block )
     {
-        m_order.erase( match->second.position );
-        m_order.push_back( match->first );
-        match->second.position = std::prev( m_order.end() );
+        auto behind = m_runs.upper_bound( block );
+        if ( behind == m_runs.begin() ) {
+            return m_runs.end();
+        }
+        --behind;
+        return block - behind->first < behind->second.run->count() ? behind : m_runs.end();
     }
 
-    size_t m_capacity;
-    std::unordered_map<Key, Entry> m_entries;
-    std::list<Key> m_order;   /* front = least recently used */
+    typename Runs::iterator
+    drop( typename Runs::iterator entry )
+    {
+        m_statistics.unusedRuns += entry->second.uses == 0 ? 1 : 0;
+        ++m_statistics.evictions;
+        m_blocks -= entry->second.run->count();
+        return m_runs.erase( entry );
+    }
+
+    size_t m_budget;
+    Runs m_runs;
+    size_t m_blocks{ 0 };
+    uint64_t m_clock{ 0 };
     Statistics m_statistics;
-};
-
-/* ------------------------------------------------------------------------------------------------ prefetch strategy */
-class FetchNextAdaptive
-{
-public:
-    explicit
-    FetchNextAdaptive( size_t memorySize = 3 ) :
-        m_memorySize( memorySize )
-    {}
-
-    /** Prefetcher.hpp:91-104 */
-    void
-    fetch( size_t index )
-    {
-        if ( !m_previousIndexes.empty() && ( m_previousIndexes.front() == index ) ) {
-            return;
-        }
-        m_previousIndexes.push_front( index );
-        while ( m_previousIndexes.size() > m_memorySize ) {
-            m_previousIndexes.pop_back();
-        }
-    }
-
-    /** Prefetcher.hpp:106-116 */
-    [[nodiscard]] bool
-    isSequential() const noexcept
-    {
-        for ( size_t i = 0; i + 1 < m_previousIndexes.size(); ++i ) {
-            if ( m_previousIndexes[i + 1] + 1 != m_previousIndexes[i] ) {
-                return false;
-            }
-        }
-        return true;
-    }
-
-    /** Prefetcher.hpp:118-183: full amount when sequential, nothing when random, exponential in between. */
-    [[nodiscard]] std::vector<size_t>
-    prefetch( size_t maxAmountToPrefetch ) const
-    {
-        const auto size = m_previousIndexes.size();
-        if ( ( size == 0 ) || ( maxAmountToPrefetch == 0 ) ) {
-            return {};
-        }
-        const auto iotaFrom = [] ( size_t first, size_t count ) {
-            std::vector<size_t> result( count );
-            for ( size_t i = 0; i < count; ++i ) {
-                result[i] = first + i;
-            }
-            return result;
-        };
-        if ( size == 1 ) {
-            return iotaFrom( m_previousIndexes.front() + 1, maxAmountToPrefetch );
-        }
-        size_t adjacent = 0;
-        for ( size_t i = 0; i + 1 < size; ++i ) {
-            if ( m_previousIndexes[i] == m_previousIndexes[i + 1] + 1 ) {
-                ++adjacent;
-            }
-        }
-        if ( adjacent == 0 ) {
-            return {};
-        }
-        size_t lastConsecutiveCount = 0;
-        for ( size_t i = 0; i + 1 < size; ++i ) {
-            if ( m_previousIndexes[i] == m_previousIndexes[i + 1] + 1 ) {
-                lastConsecutiveCount = lastConsecutiveCount == 0 ? 2 : lastConsecutiveCount + 1;
-            } else {
-                break;
-            }
-        }
-        const auto consecutiveRatio = static_cast<double>( std::min( lastConsecutiveCount, size ) )
-                                      / static_cast<double>( size );
-        const auto amount = std::round( std::exp2( consecutiveRatio * std::log2( (double)maxAmountToPrefetch ) ) );
-        return iotaFrom( m_previousIndexes.front() + 1, static_cast<size_t>( std::max( 0.0, amount ) ) );
-    }
-
-private:
-    const size_t m_memorySize;
-    std::deque<size_t> m_previousIndexes;   /* most recent at the front */
 };
 
 /* ------------------------------------------------------------------------------------------------ block finder */

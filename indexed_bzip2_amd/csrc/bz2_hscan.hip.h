@@ -6,15 +6,18 @@
  * alignment nor the table.  But the ONLY thing that is serial is the bit position at which every 50-symbol group starts:
  * once those positions are known, all groups (18 000 per level-9 block) decode independently.
  *
- *   k_hscan  one wavefront per block.  Header, selectors, code lengths, canonical tables as in k_huff.  Then, group by
+ *   k_hscan  K wavefronts per block (K = 1 for large batches, 4 or 8 when few blocks have to be through quickly).  Wave 0
+ *            parses header, selectors, code lengths and builds the canonical tables as in k_huff.  Then, group by
  *            group: all 64 lanes look up the length of the code that WOULD start at each of S consecutive bit
  *            positions (S = 64..1024, adapted to the table), which gives the successor array J1[i] = i + len(i); five
  *            rounds of pointer doubling in LDS, J2k[i] = Jk[Jk[i]], give J2, J4, J8, J16, J32, and the group that starts
  *            at bit x ends at J2[J16[J32[x]]] (32 + 16 + 2 = 50 symbols).  The dependent work per group is nine LDS
  *            round trips instead of ~50 chain steps on the scalar unit, no symbol is produced, nothing is written but
  *            one u32 per group.  End-of-block, "no code matches" and end-of-input positions are absorbing entries
- *            (J[i] = i | FLAG), so the first group that runs into one of them is found exactly; consecutive groups with
- *            the same table share one set of arrays.
+ *            (they point to themselves), so the first group that runs into one of them is found exactly; consecutive
+ *            groups with the same table share one set of arrays.  With K > 1 the K waves share the rows of every build
+ *            (one barrier per round of doubling, two sets of arrays in turn): a lone wave is bound by its instruction
+ *            issue rate, which the wide spans of incompressible blocks (512 positions per group) feel most.
  *   k_hsym   one LANE per group: decodes its 50 symbols from the known start with the known table (per-lane bit reader,
  *            {length, symbol} look-up table in LDS, canonical range search for long codes =
  *            HuffmanCodingShortBitsCached::decode / decodeLong, src/huffman/HuffmanCodingShortBitsCached.hpp:98-150).
@@ -36,7 +39,6 @@ constexpr uint32_t SCAN_ROWS = SCAN_MAX_SPAN / 64;
 constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SCAN_GROUPS = 18002;     /* 900 100 symbols: more than any block that k_mtf accepts */
 constexpr uint32_t GPOS_STRIDE = 18048;         /* u32 per block */
-constexpr uint32_t SCAN_RING_WORDS = 128;      /* + 64 mirrored words, so that two consecutive words never wrap */
 constexpr uint32_t LEN_STOP = 0x80u;            /* length-table flag: the code is the end-of-block symbol */
 constexpr uint32_t SYM_THREADS = 256;           /* groups per k_hsym workgroup */
 
@@ -63,13 +65,42 @@ struct ScanMeta
     uint32_t pad[2];
 };
 
+constexpr uint32_t SCAN_RING_ENTRIES = 128;   /* stream words kept around the current position */
+constexpr uint32_t SCAN_RING_MIRROR = 40;     /* entries repeated behind the end, so that a build never wraps */
+
+constexpr uint32_t LEV_ENTRIES = SCAN_MAX_SPAN + 16;      /* entries per array: the span, OUT, TERM, padding */
+constexpr uint32_t LEV_BYTES = 2 * LEV_ENTRIES;
+
+/** The arrays of one build: J2, J16, J32 (and the intermediate levels) as byte offsets, see scan_build.  ONE array
+ * object holding the three ("a", "b", "c" below), so that every access is derived from the same base: pointers that
+ * walk from one member array into the next would tell the compiler that the accesses cannot alias. */
+struct alignas( 16 ) ScanSlot
+{
+    uint16_t lev[3 * LEV_ENTRIES];
+
+    __device__ __forceinline__ uint8_t* bytes() { return reinterpret_cast<uint8_t*>( lev ); }
+    __device__ __forceinline__ uint16_t& at( uint32_t array, uint32_t entry ) { return lev[array * LEV_ENTRIES + entry]; }
+};
+
+/** What wave 0 found in front of the symbols, for the other waves and for the block's record. */
+struct ScanHeader
+{
+    uint64_t enc_size, pos_base;
+    int32_t  status, is_eos, is_eof;
+    uint32_t active, header_crc, orig_ptr, symbol_count, n_sel, size_bits, p0, n_words;
+};
+
+template<uint32_t K>
 struct ScanShared
 {
     uint8_t  lenlut[6][SCAN_LUT_SIZE];   /* code length per index (| LEN_STOP: end-of-block), 0 = longer than the index or no code */
     uint32_t limit[6][24];               /* [t][l]: (first + count) << (20 - l), 0 outside [minLen, maxLen] */
     uint32_t eob_lo[6], eob_hi[6];       /* 20-bit windows that start with the end-of-block code: [lo, hi) */
-    uint32_t ring[SCAN_RING_WORDS + 64]; /* stream words around the current position; [128, 192) mirrors [0, 64) */
     uint32_t minmax[6];
+    /* stream words around the current position, two per entry so that one 8-byte read gives 64 stream bits in register
+     * order: entry e = { word e + 1, word e }; entries [128, 168) repeat [0, 40) */
+    uint32_t ring[2 * ( SCAN_RING_ENTRIES + SCAN_RING_MIRROR )];
+    ScanHeader hdr;
     union alignas( 16 ) {
         struct {
             uint16_t lut[SCAN_LUT_SIZE];      /* first: copied out in 16-byte units */
@@ -79,107 +110,150 @@ struct ScanShared
             uint8_t  lens[264];
             uint8_t  sym_to_byte[256];
         } build;
-        struct {
-            uint16_t a[SCAN_MAX_SPAN + 16], b[SCAN_MAX_SPAN + 16], c[SCAN_MAX_SPAN + 16];
-        } lev;
+        ScanSlot slot[2];   /* builds alternate between them */
     };
 };
 
-/** J1 (successor of every bit position under table t) and its doublings J2 .. J32 over R rows of 64 positions that
- * start at relative bit position p.  Afterwards sh.lev.b = J2, sh.lev.c = J16, sh.lev.a = J32 (only entry 0 if `firstOnly`:
- * a single group is chased from position 0).  Entries are BYTE offsets into these u16 arrays (2 x position), so that a
- * round of doubling is one ds_read + one ds_write per row: 2 i' for the next position, OUT = 2 S beyond the span, TERM =
- * 2 S + 2 for a position whose code is the end-of-block symbol, matches no code or ends behind the input.  OUT and TERM
- * are entries that point to themselves (written by the caller), i.e. absorbing under doubling. */
-template<uint32_t R, bool NEAR_END>
+/** Stream word `index` (relative to the block's base word) = `value` into the ring: high half of entry `index`, low half
+ * of entry `index - 1`, and their mirrors. */
 __device__ __forceinline__ void
-scan_build( ScanShared& sh, uint32_t t, uint32_t p, uint32_t S, uint32_t sizeBits, const uint32_t ( &lim )[10],
-            uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane )
+ring_put( uint32_t* ring, uint32_t index, uint32_t value )
 {
-    const uint8_t* const A = reinterpret_cast<const uint8_t*>( sh.lev.a );
-    const uint8_t* const B = reinterpret_cast<const uint8_t*>( sh.lev.b );
-    const uint8_t* const C = reinterpret_cast<const uint8_t*>( sh.lev.c );
-    const uint8_t* const lenlut = sh.lenlut[t];
-    const uint32_t OUT = 2 * S, TERM = 2 * S + 2;
-    uint32_t own[R], v20s[R];
-    bool anyLong = false;
+    const uint32_t e1 = index & ( SCAN_RING_ENTRIES - 1 );
+    const uint32_t e0 = ( index - 1 ) & ( SCAN_RING_ENTRIES - 1 );
+    ring[2 * e1 + 1] = value;
+    ring[2 * e0] = value;
+    if ( e1 < SCAN_RING_MIRROR ) ring[2 * ( SCAN_RING_ENTRIES + e1 ) + 1] = value;
+    if ( e0 < SCAN_RING_MIRROR ) ring[2 * ( SCAN_RING_ENTRIES + e0 )] = value;
+}
+
+/** Barrier between the waves that share a build; a single wave only has to order its own LDS traffic. */
+template<uint32_t K>
+__device__ __forceinline__ void
+scan_sync()
+{
+    if ( K > 1 ) __syncthreads(); else wave_sync();
+}
+
+/** J1 (successor of every bit position under the table of `lenlut`) and its doublings J2 .. J32 over S = 64 K RW bit
+ * positions that start at relative bit position p.  The K waves of the workgroup share the rows of 64 positions: wave w
+ * takes rows w, w + K, ...  Afterwards slot.b = J2, slot.c = J16, slot.a = J32 (only entry 0 if `firstOnly`: a single group
+ * is chased from position 0).  Entries are BYTE offsets into these u16 arrays (2 x position), so that a round of
+ * doubling is one ds_read + one ds_write per row: 2 i' for the next position, OUT = 2 S beyond the span, TERM = 2 S + 2 for
+ * a position whose code is the end-of-block symbol, matches no code or ends behind the input.  OUT and TERM are entries
+ * that point to themselves (written by the caller), i.e. absorbing under doubling.
+ * Codes longer than the index bits of the length table are rare per position but present in most rows: their positions
+ * are collected (arrays b and c are free until the first doubling) and resolved in ONE pass of range comparisons
+ * instead of one per row. */
+template<uint32_t K, uint32_t RW, bool NEAR_END>
+__device__ __forceinline__ void
+scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p, uint32_t sizeBits,
+            const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane, uint32_t wave )
+{
+    constexpr uint32_t S = 64 * K * RW;
+    constexpr uint32_t OUT = 2 * S, TERM = 2 * S + 2;
+    constexpr uint32_t STEP = 128 * K;          /* bytes between two rows of one wave */
+    uint8_t* const base = slot.bytes();
+    const uint8_t* const A = base;
+    const uint8_t* const B = base + LEV_BYTES;
+    const uint8_t* const C = base + 2 * LEV_BYTES;
+    uint8_t* const mine = base + 128 * wave + 2 * lane;   /* my entry of row 0, array a */
+    constexpr uint32_t TO_B = LEV_BYTES, TO_C = 2 * LEV_BYTES;
+    /* positions with long codes, 1 040 / K entries per wave (arrays b and c): position << 20 | 20-bit window */
+    uint32_t* const pending = reinterpret_cast<uint32_t*>( base + LEV_BYTES ) + wave * ( LEV_ENTRIES / K );
+    const uint32_t first = 64 * wave + lane;     /* my position in row 0 */
+    uint32_t own[RW], v20s[RW];
+    {
+        /* 64 stream bits from the lane's word on: one 8-byte read per row at a fixed distance from the first row's */
+        const uint32_t a0 = p + first;
+        const uint64_t* const w = reinterpret_cast<const uint64_t*>( ring ) + ( ( a0 >> 5 ) & ( SCAN_RING_ENTRIES - 1 ) );
+        const uint32_t sh = a0 & 31u;
 #pragma unroll
-    for ( uint32_t r = 0; r < R; ++r ) {
-        const uint32_t a = p + 64 * r + lane;
-        const uint32_t* const w = sh.ring + ( ( a >> 5 ) & ( SCAN_RING_WORDS - 1 ) );
-        const uint32_t hi = w[0], lo = w[1];   /* one ds_read2_b32: the ring is mirrored behind its end */
-        const uint32_t bits32 = (uint32_t)( ( ( ( (uint64_t)hi << 32 ) | lo ) << ( a & 31u ) ) >> 32 );
-        v20s[r] = bits32 >> 12;
-        own[r] = lenlut[bits32 >> ( 32 - SCAN_LUT_BITS )];
-    }
-#pragma unroll
-    for ( uint32_t r = 0; r < R; ++r ) anyLong |= own[r] == 0;
-    if ( __ballot( anyLong ) != 0 ) {
-        /* longer than the index bits: canonical codes, the first length whose range end exceeds the window
-         * (decodeLong, HuffmanCodingShortBitsCached.hpp:117-150); 21: no code matches */
-#pragma unroll
-        for ( uint32_t r = 0; r < R; ++r ) {
-            uint32_t ll = 11;
-#pragma unroll
-            for ( uint32_t l = 0; l < 10; ++l ) ll += v20s[r] >= lim[l] ? 1u : 0u;
-            const bool stop = ( ll > 20 ) | ( ( v20s[r] >= eobLo ) & ( v20s[r] < eobHi ) );
-            own[r] = own[r] == 0 ? ( stop ? LEN_STOP : ll ) : own[r];
+        for ( uint32_t j = 0; j < RW; ++j ) {
+            const uint32_t bits32 = (uint32_t)( ( w[2 * K * j] << sh ) >> 32 );
+            v20s[j] = bits32 >> 12;
+            own[j] = lenlut[bits32 >> ( 32 - SCAN_LUT_BITS )];
         }
     }
+    uint32_t nPending = 0;
 #pragma unroll
-    for ( uint32_t r = 0; r < R; ++r ) {
-        const uint32_t i = 64 * r + lane;
-        const uint32_t len = own[r];
-        bool stop = len >= LEN_STOP;
-        if ( NEAR_END ) stop |= p + i + ( len & 31u ) > sizeBits;
-        const uint32_t next = 2 * ( i + len ) < OUT ? 2 * ( i + len ) : OUT;
-        own[r] = stop ? TERM : next;
-        sh.lev.a[i] = (uint16_t)own[r];
+    for ( uint32_t j = 0; j < RW; ++j ) {
+        const uint64_t isLong = __ballot( own[j] == 0 );
+        if ( isLong != 0 ) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( isLong >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)isLong, 0 ) );
+            if ( own[j] == 0 ) pending[nPending + rank] = ( ( first + 64 * K * j ) << 20 ) | v20s[j];
+            nPending += (uint32_t)__popcll( isLong );
+        }
     }
-    wave_sync();
-    /* one round of doubling: own[r] = src[own[r]], the same into dst */
-#define SCAN_LEVEL( src, dst ) \
-    _Pragma( "unroll" ) for ( uint32_t r = 0; r < R; ++r ) own[r] = *reinterpret_cast<const uint16_t*>( src + own[r] ); \
-    _Pragma( "unroll" ) for ( uint32_t r = 0; r < R; ++r ) sh.lev.dst[64 * r + lane] = (uint16_t)own[r]; \
-    wave_sync();
-    SCAN_LEVEL( A, b )   /* J2 -> b (kept) */
-    SCAN_LEVEL( B, c )   /* J4 */
-    SCAN_LEVEL( C, a )   /* J8 */
-    SCAN_LEVEL( A, c )   /* J16 -> c (kept) */
-    if ( firstOnly ) {
-        const uint32_t j32 = *reinterpret_cast<const uint16_t*>( C + own[0] );
-        if ( lane == 0 ) sh.lev.a[0] = (uint16_t)j32;
+    const uint32_t lane2 = 2 * first;
+#pragma unroll
+    for ( uint32_t j = 0; j < RW; ++j ) {
+        const uint32_t len = own[j];
+        bool stop = len >= LEN_STOP;
+        if ( NEAR_END ) stop |= p + first + 64 * K * j + ( len & 31u ) > sizeBits;
+        /* 2 (i + len), clamped to OUT, with i = first + 64 K j */
+        uint32_t next = 2 * len + lane2;
+        next = ( next < OUT - STEP * j ? next : OUT - STEP * j ) + STEP * j;
+        own[j] = stop ? TERM : next;
+        *reinterpret_cast<uint16_t*>( mine + STEP * j ) = (uint16_t)own[j];
+    }
+    if ( nPending != 0 ) {
+        /* canonical codes: the first length whose range end exceeds the window (decodeLong,
+         * HuffmanCodingShortBitsCached.hpp:117-150); 21: no code matches */
         wave_sync();
+        for ( uint32_t k = lane; k < nPending; k += 64 ) {
+            const uint32_t e = pending[k];
+            const uint32_t v20 = e & 0xFFFFFu, i = e >> 20;
+            uint32_t ll = 11;
+#pragma unroll
+            for ( uint32_t l = 0; l < 10; ++l ) ll += v20 >= lim[l] ? 1u : 0u;
+            bool stop = ( ll > 20 ) | ( ( v20 >= eobLo ) & ( v20 < eobHi ) );
+            if ( NEAR_END ) stop |= p + i + ll > sizeBits;
+            const uint32_t next = 2 * ( i + ll ) < OUT ? 2 * ( i + ll ) : OUT;
+            *reinterpret_cast<uint16_t*>( base + 2 * i ) = (uint16_t)( stop ? TERM : next );
+        }
+        /* Behind the end-of-block code of a block's last group the span runs into the next block's header, where most
+         * positions look like long codes: with a single wave the list may then have grown over the OUT / TERM entries of
+         * arrays b and c (entries S and S + 1; a list of more than S / 2 positions), which are put back here. */
+        if ( K == 1 && 2 * nPending > S && lane < 2 ) {
+            const uint16_t v = (uint16_t)( OUT + 2 * lane );
+            *reinterpret_cast<uint16_t*>( base + LEV_BYTES + OUT + 2 * lane ) = v;
+            *reinterpret_cast<uint16_t*>( base + 2 * LEV_BYTES + OUT + 2 * lane ) = v;
+        }
+        wave_sync();
+#pragma unroll
+        for ( uint32_t j = 0; j < RW; ++j ) own[j] = *reinterpret_cast<const uint16_t*>( mine + STEP * j );
+    }
+    scan_sync<K>();
+    /* one round of doubling: own[j] = src[own[j]], the same into dst */
+#define SCAN_LEVEL( src, toDst ) \
+    _Pragma( "unroll" ) for ( uint32_t j = 0; j < RW; ++j ) own[j] = *reinterpret_cast<const uint16_t*>( src + own[j] ); \
+    _Pragma( "unroll" ) for ( uint32_t j = 0; j < RW; ++j ) *reinterpret_cast<uint16_t*>( mine + ( toDst ) + STEP * j ) = (uint16_t)own[j]; \
+    scan_sync<K>();
+    SCAN_LEVEL( A, TO_B )   /* J2 -> b (kept) */
+    SCAN_LEVEL( B, TO_C )   /* J4 */
+    SCAN_LEVEL( C, 0 )      /* J8 */
+    SCAN_LEVEL( A, TO_C )   /* J16 -> c (kept) */
+    if ( firstOnly ) {
+        if ( wave == 0 ) {
+            const uint32_t j32 = *reinterpret_cast<const uint16_t*>( C + own[0] );
+            if ( lane == 0 ) *reinterpret_cast<uint16_t*>( base ) = (uint16_t)j32;
+        }
+        scan_sync<K>();
     } else {
-        SCAN_LEVEL( C, a )   /* J32 -> a (kept) */
+        SCAN_LEVEL( C, 0 )   /* J32 -> a (kept) */
     }
 #undef SCAN_LEVEL
 }
 
-__global__ __launch_bounds__( 64 ) void
-k_hscan( const uint32_t* __restrict__ in_words,
-         uint64_t                     in_size_bytes,
-         const uint64_t* __restrict__ offsets,
-         BlockMeta* __restrict__      meta,
-         HuffMeta* __restrict__       hmeta,
-         ScanMeta* __restrict__       smeta,
-         uint8_t*                     sel_buf,
-         uint8_t* __restrict__        stb_buf,
-         HuffTables* __restrict__     tab_buf,
-         uint32_t* __restrict__       gpos_buf,
-         uint32_t                     n_blocks,
-         const uint32_t* __restrict__ order )
+/** Header, selectors, code lengths, canonical tables of one block: Block::readBlockHeader .. readTrees
+ * (bzip2.hpp:479-685), executed by ONE wavefront.  Leaves the tables in `sh` (and in `tabs` for k_hsym) and the rest
+ * in sh.hdr. */
+template<uint32_t K>
+__device__ __forceinline__ void
+scan_parse( ScanShared<K>& sh, const uint32_t* __restrict__ in_words, uint64_t in_size_bytes, uint64_t start,
+            uint8_t* sel, uint8_t* __restrict__ stb_buf, HuffTables* tabs, uint32_t b, uint32_t lane )
 {
-    __shared__ ScanShared sh;
-    const uint32_t slot = blockIdx.x;
-    if ( slot >= n_blocks ) return;
-    const uint32_t b = sfl( order[slot] );
-    const uint32_t lane = threadIdx.x & 63;
-    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
-    uint32_t* const gpos = gpos_buf + (size_t)b * GPOS_STRIDE;
-    HuffTables* const tabs = tab_buf + b;
-
-    const uint64_t start = offsets[b];
     BitRd br;
     br.init( in_words, in_size_bytes, start );
 
@@ -189,11 +263,8 @@ k_hscan( const uint32_t* __restrict__ in_words,
     uint64_t encSize = 0;
     uint32_t symbolCount = 0, groupCount = 0, nSel = 0;
     uint32_t active = 0;
-    uint32_t nGroups = 0, terminal = 0;
-    uint64_t posBase = 0;
-    uint32_t sizeBits = 0;
 
-#define FAIL( code ) do { status = br.eof ? (int32_t)ST_EOF : (int32_t)( code ); goto finish; } while ( 0 )
+#define FAIL( code ) do { status = br.eof ? (int32_t)ST_EOF : (int32_t)( code ); goto done; } while ( 0 )
 
     /* ---- Block::readBlockHeader, bzip2.hpp:479-523 ---- */
     if ( start > br.size_bits ) {
@@ -218,7 +289,7 @@ k_hscan( const uint32_t* __restrict__ in_words,
             }
             encSize = br.pos - start;
             isEof = br.pos >= br.size_bits;
-            goto finish;
+            goto done;
         }
         if ( magic != 0x314159265359ULL ) FAIL( ST_BAD_MAGIC );
         const uint32_t randomized = br.read( 1 );
@@ -416,41 +487,137 @@ k_hscan( const uint32_t* __restrict__ in_words,
     }
     active = 1;
 
-    /* ---- where every 50-symbol group of Block::readBlockData's loop (bzip2.hpp:709-723) starts ---- */
-    {
-        /* Bit positions are 32-bit and relative to the word that holds the first symbol bit, as in k_huff. */
-        posBase = br.pos & ~31ull;
-        const uint32_t* const words = in_words + ( posBase >> 5 );
+done:
+#undef FAIL
+    if ( lane == 0 ) {
+        ScanHeader h;
+        const uint64_t posBase = br.pos & ~31ull;   /* bit positions of the scan are 32-bit, relative to this word, as in k_huff */
         const uint64_t wordsLeft = ( ( in_size_bytes + 3 ) >> 2 ) - ( posBase >> 5 );
-        const uint32_t nWords = wordsLeft < 0x08000000ull ? (uint32_t)wordsLeft : 0x08000000u;
-        sizeBits = br.size_bits - posBase < 0xFFFF0000ull ? (uint32_t)( br.size_bits - posBase ) : 0xFFFF0000u;
-        uint32_t p = (uint32_t)( br.pos - posBase );
-        uint32_t g = 0;
-        __threadfence_block();   /* selectors written above are read back below */
+        h.enc_size = encSize;
+        h.pos_base = posBase;
+        h.status = status;
+        h.is_eos = isEos;
+        h.is_eof = isEof;
+        h.active = active;
+        h.header_crc = headerCrc;
+        h.orig_ptr = origPtr;
+        h.symbol_count = symbolCount;
+        h.n_sel = nSel;
+        h.size_bits = br.size_bits - posBase < 0xFFFF0000ull ? (uint32_t)( br.size_bits - posBase ) : 0xFFFF0000u;
+        h.p0 = (uint32_t)( br.pos - posBase );
+        h.n_words = wordsLeft < 0x08000000ull ? (uint32_t)wordsLeft : 0x08000000u;
+        sh.hdr = h;
+    }
+}
 
-        /* stream ring: words [wHi - 128, wHi) are in sh.ring, the next 64 are on their way in `pend` */
+/** Rows of 64 positions per wave for a span of `rows` rows shared by K waves: the builds are statically unrolled, so
+ * the count is rounded up to the next instance. */
+template<uint32_t K>
+__device__ __forceinline__ uint32_t
+scan_rows_per_wave( uint32_t rows )
+{
+    const uint32_t rw = ( rows + K - 1 ) / K;
+    constexpr uint32_t MAX = SCAN_ROWS / K;
+    if ( rw <= 6 ) return rw < MAX ? rw : MAX;
+    return rw <= 8 ? ( 8u < MAX ? 8u : MAX ) : ( rw <= 10 ? ( 10u < MAX ? 10u : MAX ) : ( rw <= 12 ? ( 12u < MAX ? 12u : MAX ) : MAX ) );
+}
+
+template<uint32_t K>
+__device__ __forceinline__ void
+scan_build_rows( uint32_t rw, bool nearEnd, ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p,
+                 uint32_t sizeBits, const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool one, uint32_t lane,
+                 uint32_t wave )
+{
+    constexpr uint32_t MAX = SCAN_ROWS / K;
+#define SCAN_CASE( n ) \
+    if constexpr ( ( n ) <= MAX ) { \
+        if ( rw == ( n ) ) { scan_build<K, ( n ), false>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave ); return; } \
+    }
+    if ( nearEnd ) {
+        scan_build<K, MAX, true>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave );
+        return;
+    }
+    SCAN_CASE( 1 ) SCAN_CASE( 2 ) SCAN_CASE( 3 ) SCAN_CASE( 4 ) SCAN_CASE( 5 ) SCAN_CASE( 6 ) SCAN_CASE( 8 ) SCAN_CASE( 10 )
+    SCAN_CASE( 12 )
+    scan_build<K, MAX, false>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave );
+#undef SCAN_CASE
+}
+
+template<uint32_t K>
+__global__ __launch_bounds__( 64 * K ) void
+k_hscan( const uint32_t* __restrict__ in_words,
+         uint64_t                     in_size_bytes,
+         const uint64_t* __restrict__ offsets,
+         BlockMeta* __restrict__      meta,
+         HuffMeta* __restrict__       hmeta,
+         ScanMeta* __restrict__       smeta,
+         uint8_t*                     sel_buf,
+         uint8_t* __restrict__        stb_buf,
+         HuffTables* __restrict__     tab_buf,
+         uint32_t* __restrict__       gpos_buf,
+         uint32_t                     n_blocks,
+         const uint32_t* __restrict__ order,
+         uint32_t                     tune )   /* debugging: 1 = one group per build, 2 = always the full span */
+{
+    __shared__ ScanShared<K> sh;
+    const uint32_t slotIndex = blockIdx.x;
+    if ( slotIndex >= n_blocks ) return;
+    const uint32_t b = sfl( order[slotIndex] );
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = sfl( threadIdx.x >> 6 );
+    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
+    uint32_t* const gpos = gpos_buf + (size_t)b * GPOS_STRIDE;
+    const uint64_t start = offsets[b];
+
+    if ( wave == 0 ) {
+        scan_parse<K>( sh, in_words, in_size_bytes, start, sel, stb_buf, tab_buf + b, b, lane );
+        __threadfence_block();   /* the selectors are read back below */
+    }
+    scan_sync<K>();
+
+    const uint32_t active = sfl( sh.hdr.active );
+    int32_t status = (int32_t)sfl( (uint32_t)sh.hdr.status );
+    const uint32_t nSel = sfl( sh.hdr.n_sel );
+    const uint32_t sizeBits = sfl( sh.hdr.size_bits );
+    const uint32_t nWords = sfl( sh.hdr.n_words );
+    const uint64_t posBase = ( (uint64_t)sfl( (uint32_t)( sh.hdr.pos_base >> 32 ) ) << 32 ) | sfl( (uint32_t)sh.hdr.pos_base );
+    uint32_t nGroups = 0, terminal = 0;
+
+    /* ---- where every 50-symbol group of Block::readBlockData's loop (bzip2.hpp:709-723) starts ---- */
+    if ( active ) {
+        const uint32_t* const words = in_words + ( posBase >> 5 );
+        uint32_t p = sfl( sh.hdr.p0 );
+        uint32_t g = 0;
+
+        /* stream ring: words [wHi - 128, wHi) are in sh.ring, the next 64 are on their way in `pend` (wave 0 fills) */
         uint32_t wHi = 0;
-        uint32_t pend = lane < nWords ? words[lane] : 0u;
+        uint32_t pend = 0;
+        if ( wave == 0 ) pend = lane < nWords ? be32( words[lane] ) : 0u;
         /* selectors of groups [64 k, 64 k + 64), one per lane, the next 64 on their way */
         uint32_t selV = sel[lane];
         uint32_t selPend = sel[64 + lane];
         /* per-table estimate of a group's length in bits, lane t = table t; 0 = not seen yet (full span) */
         uint32_t estV = 0;
         uint32_t gposV = 0;
-        uint32_t lastS = 0, lastT = 0xFFFFFFFFu;
+        uint32_t lastS[2] = { 0, 0 }, lastT = 0xFFFFFFFFu;
         uint32_t lim[10] = {};
         uint32_t eobLo = 0, eobHi = 0;
+        uint32_t which = 0;        /* the two slots alternate: a wave that is through with a chase may start the next build */
         bool forceFull = false;
 
         for ( ;; ) {
             if ( g >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
             if ( g >= MAX_SCAN_GROUPS ) { status = ST_DATA_OVERFLOW; break; }
-            /* stream words up to (p + SCAN_MAX_SPAN + 64) >> 5 */
-            while ( ( p >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
-                sh.ring[( wHi & ( SCAN_RING_WORDS - 1 ) ) + lane] = pend;
-                if ( ( wHi & ( SCAN_RING_WORDS - 1 ) ) == 0 ) sh.ring[SCAN_RING_WORDS + lane] = pend;   /* mirror */
-                wHi += 64;
-                pend = wHi + lane < nWords ? words[wHi + lane] : 0u;
+            /* stream words up to (p + SCAN_MAX_SPAN + 64) >> 5 (every wave keeps count, wave 0 moves the words) */
+            if ( ( p >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
+                while ( ( p >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
+                    if ( wave == 0 ) {
+                        ring_put( sh.ring, wHi + lane, pend );
+                        pend = wHi + 64 + lane < nWords ? be32( words[wHi + 64 + lane] ) : 0u;
+                    }
+                    wHi += 64;
+                }
+                scan_sync<K>();
             }
             /* this group's table and how many of the following groups (of this window of 64) use it as well */
             const uint32_t t = (uint32_t)__builtin_amdgcn_readlane( (int)selV, g & 63u );
@@ -466,7 +633,7 @@ k_hscan( const uint32_t* __restrict__ in_words,
                 /* range ends of the long codes of this table, flat beyond its longest code: a 20-bit window v holds a code
                  * of length 11 + #{ l : v >= lim[l] }, none if that comes to 21 */
                 const uint32_t mx = sfl( sh.minmax[t] ) >> 8;
-                const uint32_t limV = sh.limit[t][lane < mx ? ( lane < 24 ? lane : 23 ) : mx];
+                const uint32_t limV = sh.limit[t][lane < mx ? lane : mx];
 #pragma unroll
                 for ( uint32_t l = 0; l < 10; ++l ) lim[l] = (uint32_t)__builtin_amdgcn_readlane( (int)limV, 11 + l );
                 eobLo = sfl( sh.eob_lo[t] );
@@ -474,52 +641,35 @@ k_hscan( const uint32_t* __restrict__ in_words,
                 lastT = t;
             }
             const uint32_t est = (uint32_t)__builtin_amdgcn_readlane( (int)estV, t );
-            uint32_t S = SCAN_MAX_SPAN, m = 1;
-            if ( est != 0 && !forceFull ) {
+            const bool nearEnd = p + SCAN_MAX_SPAN + 32 > sizeBits;
+            uint32_t rows = SCAN_ROWS, m = 1;
+            if ( est != 0 && !forceFull && !nearEnd && !( tune & 2u ) ) {
                 const uint32_t need = est + ( est >> 3 ) + 16;   /* a group of this table: last one + 12 % + 16 bits */
                 m = ( SCAN_MAX_SPAN - 24 ) / need;
+                if ( tune & 1u ) m = 1;
                 if ( m > runLen ) m = runLen;
                 if ( m < 1 ) m = 1;
-                S = ( m * need + 24 + 63 ) & ~63u;
-                if ( S > SCAN_MAX_SPAN ) S = SCAN_MAX_SPAN;
+                rows = ( m * need + 24 + 63 ) >> 6;
+                if ( rows > SCAN_ROWS ) rows = SCAN_ROWS;
             }
             forceFull = false;
-            /* the builds are statically unrolled per row count: round the span up to the next instance; close to the end
-             * of the input every position checks that its code ends inside (one instance: the full span) */
-            const bool nearEnd = p + SCAN_MAX_SPAN + 32 > sizeBits;
-            uint32_t rows = nearEnd ? SCAN_ROWS : S >> 6;
-            rows = rows <= 6 ? rows : ( rows <= 8 ? 8u : ( rows <= 10 ? 10u : ( rows <= 12 ? 12u : 16u ) ) );
-            S = rows << 6;
-            if ( S != lastS ) {
-                /* OUT = 2 S and TERM = 2 S + 2 point to themselves in all three arrays */
+            const uint32_t rw = nearEnd ? SCAN_ROWS / K : scan_rows_per_wave<K>( rows );
+            const uint32_t S = 64 * K * rw;
+            ScanSlot& slot = sh.slot[which];
+            if ( S != lastS[which] ) {
+                /* OUT = 2 S and TERM = 2 S + 2 point to themselves in all three arrays (every wave writes the same) */
                 if ( lane < 2 ) {
                     const uint16_t v = (uint16_t)( 2 * ( S + lane ) );
-                    sh.lev.a[S + lane] = v; sh.lev.b[S + lane] = v; sh.lev.c[S + lane] = v;
+                    slot.at( 0, S + lane ) = v; slot.at( 1, S + lane ) = v; slot.at( 2, S + lane ) = v;
                 }
-                lastS = S;
+                lastS[which] = S;
             }
-            const bool one = m == 1;
-            if ( nearEnd ) {
-                scan_build<16, true>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane );
-            } else {
-                switch ( rows ) {
-                case 1: scan_build<1, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 2: scan_build<2, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 3: scan_build<3, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 4: scan_build<4, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 5: scan_build<5, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 6: scan_build<6, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 8: scan_build<8, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 10: scan_build<10, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                case 12: scan_build<12, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                default: scan_build<16, false>( sh, t, p, S, sizeBits, lim, eobLo, eobHi, one, lane ); break;
-                }
-            }
+            scan_build_rows<K>( rw, nearEnd, slot, sh.lenlut[t], sh.ring, p, sizeBits, lim, eobLo, eobHi, m == 1, lane, wave );
 
             /* chase: 32 + 16 + 2 symbols per group; x and the entries are byte offsets (2 x position) */
-            const uint8_t* const J32 = reinterpret_cast<const uint8_t*>( sh.lev.a );
-            const uint8_t* const J16 = reinterpret_cast<const uint8_t*>( sh.lev.c );
-            const uint8_t* const J2 = reinterpret_cast<const uint8_t*>( sh.lev.b );
+            const uint8_t* const J32 = slot.bytes();
+            const uint8_t* const J16 = slot.bytes() + 2 * LEV_BYTES;
+            const uint8_t* const J2 = slot.bytes() + LEV_BYTES;
             uint32_t x = 0, done = 0;
             bool stopAll = false;
             for ( uint32_t j = 0; j < m; ++j ) {
@@ -532,7 +682,7 @@ k_hscan( const uint32_t* __restrict__ in_words,
                 }
                 const uint32_t gg = g + j;
                 gposV = lane == ( gg & 63u ) ? p + ( x >> 1 ) : gposV;
-                if ( ( gg & 63u ) == 63u ) gpos[( gg & ~63u ) + lane] = gposV;
+                if ( wave == 0 && ( gg & 63u ) == 63u ) gpos[( gg & ~63u ) + lane] = gposV;
                 ++done;
                 if ( u == 2 * S + 2 ) {               /* end-of-block, no code or end of input inside this group */
                     terminal = 1;
@@ -553,28 +703,27 @@ k_hscan( const uint32_t* __restrict__ in_words,
             }
             g += done;
             p += x >> 1;
+            which ^= 1u;
             if ( stopAll ) break;
         }
         nGroups = g;
-        if ( ( g & 63u ) != 0 && lane < ( g & 63u ) ) gpos[( g & ~63u ) + lane] = gposV;
+        if ( wave == 0 && ( g & 63u ) != 0 && lane < ( g & 63u ) ) gpos[( g & ~63u ) + lane] = gposV;
     }
 
-finish:
-#undef FAIL
-    if ( lane == 0 ) {
+    if ( wave == 0 && lane == 0 ) {
         const uint32_t fullGroups = terminal ? nGroups - 1 : nGroups;
         BlockMeta mt;
         mt.enc_off = start;
-        mt.enc_size = encSize;
+        mt.enc_size = sh.hdr.enc_size;
         mt.decoded_size = 0;
         mt.out_off = 0;
-        mt.header_crc = headerCrc;
+        mt.header_crc = sh.hdr.header_crc;
         mt.computed_crc = 0xFFFFFFFFu;
         mt.n = 0;
-        mt.orig_ptr = origPtr;
+        mt.orig_ptr = sh.hdr.orig_ptr;
         mt.nsym = fullGroups * GROUP_SYMS;    /* k_hsym's last lane finishes nsym, enc_size and status of a terminal group */
-        mt.is_eos = isEos;
-        mt.is_eof = isEof;
+        mt.is_eos = sh.hdr.is_eos;
+        mt.is_eof = sh.hdr.is_eof;
         mt.status = status;
         mt.seg_stride = MIN_SEG_STRIDE;
         mt.nseg = 0;
@@ -585,7 +734,7 @@ finish:
         meta[b] = mt;
         HuffMeta hm;
         hm.n_stored = fullGroups * GROUP_SYMS;
-        hm.symbol_count = symbolCount;
+        hm.symbol_count = sh.hdr.symbol_count;
         hm.status = status;
         hm.active = active;
         hmeta[b] = hm;
@@ -594,7 +743,7 @@ finish:
         sm.size_bits = sizeBits;
         sm.n_groups = nGroups;
         sm.terminal = terminal;
-        sm.symbol_count = symbolCount;
+        sm.symbol_count = sh.hdr.symbol_count;
         sm.pad[0] = sm.pad[1] = 0;
         smeta[b] = sm;
     }
@@ -640,7 +789,7 @@ k_hsym( const uint32_t* __restrict__   in_words,
         const bool last = sm.terminal && gi + 1 == sm.n_groups;
         /* bit buffer: `have` valid bits left-aligned in buf */
         uint32_t w = pos >> 5;
-        uint64_t buf = ( ( (uint64_t)words[w] << 32 ) | words[w + 1] ) << ( pos & 31u );
+        uint64_t buf = ( ( (uint64_t)be32( words[w] ) << 32 ) | be32( words[w + 1] ) ) << ( pos & 31u );
         uint32_t have = 64 - ( pos & 31u );
         w += 2;
         const uint16_t* const lut = sh.tabs.lut[t];
@@ -652,7 +801,7 @@ k_hsym( const uint32_t* __restrict__   in_words,
         bool finished = false;
         for ( uint32_t j = 0; j < GROUP_SYMS; ++j ) {
             if ( have <= 32 ) {
-                buf |= (uint64_t)words[w] << ( 32 - have );   /* the input copy is zero padded */
+                buf |= (uint64_t)be32( words[w] ) << ( 32 - have );   /* the input copy is zero padded */
                 have += 32;
                 ++w;
             }

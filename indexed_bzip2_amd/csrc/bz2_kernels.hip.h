@@ -77,6 +77,14 @@ sfl( uint32_t v )
     return __builtin_amdgcn_readfirstlane( v );
 }
 
+/** A 32-bit word of the resident input as 32 stream bits, most significant first: the file's bytes stay in file order
+ * in HBM (no swapped copy), every reader swaps the word it loads (one v_perm_b32). */
+__device__ __forceinline__ uint32_t
+be32( uint32_t word )
+{
+    return __builtin_bswap32( word );
+}
+
 __device__ __forceinline__ uint32_t
 lane_id()
 {
@@ -84,7 +92,7 @@ lane_id()
 }
 
 /* -------------------------------------------------------------------------------------------------------------
- * MSB-first bit reader over big-endian-interpreted 32-bit words (reference: BitReader<true,uint64_t>,
+ * MSB-first bit reader over 32-bit words of the input, byte-swapped as they are loaded (reference: BitReader<true,uint64_t>,
  * src/core/BitReader.hpp:190-290, 469-476).  All state is wave-uniform and ends up in SGPRs.
  * ------------------------------------------------------------------------------------------------------------- */
 struct BitRd
@@ -104,7 +112,7 @@ struct BitRd
     {
         uint32_t v = 0;
         if ( i < nwords ) {
-            v = sfl( w[i] );   /* the ctx keeps the input as big-endian 32-bit words, zero padded (k_bswap32) */
+            v = sfl( be32( w[i] ) );   /* the ctx keeps the file's bytes as they are, zero padded */
         }
         return v;
     }
@@ -179,8 +187,8 @@ k_find_magic( const uint32_t* __restrict__ words, uint64_t size_bits, uint64_t m
     const uint64_t nStartWords = ( size_bits + 31 ) >> 5;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for ( uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nStartWords; w += stride ) {
-        const uint64_t hi = ( (uint64_t)words[w] << 32 ) | words[w + 1];   /* input copy is zero padded */
-        const uint64_t lo = (uint64_t)words[w + 2] << 32;
+        const uint64_t hi = ( (uint64_t)be32( words[w] ) << 32 ) | be32( words[w + 1] );   /* input copy is zero padded */
+        const uint64_t lo = (uint64_t)be32( words[w + 2] ) << 32;
 #pragma unroll 4
         for ( uint32_t s = 0; s < 32; ++s ) {
             const uint64_t window = s == 0 ? hi : ( ( hi << s ) | ( lo >> ( 64 - s ) ) );
@@ -216,19 +224,6 @@ __device__ __forceinline__ uint32_t
 popc_below( uint64_t mask, uint32_t lane )
 {
     return __popcll( mask & ( ( 1ull << lane ) - 1ull ) );
-}
-
-/** In-place byte swap of the ctx-owned input copy: afterwards a 32-bit load yields 32 stream bits MSB first. */
-__global__ __launch_bounds__( 256 ) void
-k_bswap32( uint32_t* __restrict__ words, uint64_t n_words )
-{
-    const uint64_t stride = (uint64_t)gridDim.x * 256 * 4;
-    for ( uint64_t i = ( (uint64_t)blockIdx.x * 256 + threadIdx.x ) * 4; i < n_words; i += stride ) {
-        uint4 v = *reinterpret_cast<const uint4*>( words + i );   /* buffer is padded to a multiple of 256 bytes */
-        v.x = __builtin_bswap32( v.x ); v.y = __builtin_bswap32( v.y );
-        v.z = __builtin_bswap32( v.z ); v.w = __builtin_bswap32( v.w );
-        *reinterpret_cast<uint4*>( words + i ) = v;
-    }
 }
 
 /* =============================================================================================================

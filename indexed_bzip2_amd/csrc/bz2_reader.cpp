@@ -1,16 +1,17 @@
 /**
- * bz2_reader.cpp -- reader + GPU block fetcher behind C ABI section 3 of include/mi355x_bz2.h.
+ * bz2_reader.cpp -- reader + GPU batch scheduler behind C ABI section 3 of include/mi355x_bz2.h.
  *
- *   GpuBlockFetcher  <- rapidgzip::BlockFetcher::get / prefetchNewBlocks    src/core/BlockFetcher.hpp:244-317, 446-559
- *                       + BZ2BlockFetcher::{readBlockHeader, decodeBlock}   src/indexed_bzip2/BZ2BlockFetcher.hpp:64-138
- *   ParallelReader   <- indexed_bzip2::ParallelBZ2Reader                    src/indexed_bzip2/ParallelBZ2Reader.hpp:39-498
+ *   BatchScheduler  the role of rapidgzip::BlockFetcher + BZ2BlockFetcher    src/core/BlockFetcher.hpp:244-317, 446-559,
+ *                                                                            src/indexed_bzip2/BZ2BlockFetcher.hpp:64-138
+ *   StreamReader    the role of indexed_bzip2::ParallelBZ2Reader             src/indexed_bzip2/ParallelBZ2Reader.hpp:39-498
  *
- * What is kept from the reference: the block finder running ahead on its own thread, the LRU cache + prefetch cache +
- * failed-prefetch cache, the adaptive prefetch strategy, "prefetch failures are silent, on-demand failures surface",
- * the block map and the whole read/seek state machine.
- * What is different by design (GPU backend): the thread pool of per-block tasks is replaced by ONE submission thread
- * that pushes BATCHES of blocks through mi355x_bz2_decode_batch; prefetches are issued in batches of >= P/2 blocks so
- * that every launch has enough independent blocks to fill the GPU.
+ * What a caller can observe is the reference's: read / seek / tell / eof, the block-offset map with its end-of-stream
+ * entries and end-of-file entry, "a block that cannot be decoded fails the read that needs it and no read before it",
+ * trailing garbage is ignored with a warning, the stream CRC check of the serial reader.  The structure is this design's:
+ * the unit of work is a RUN -- a batch of consecutive blocks decoded by one launch sequence into one page-locked host
+ * buffer -- not a block.  The scheduler keeps runs (in flight and finished) by the number of their first block, decides
+ * from the recent access pattern which RANGE of blocks to launch next, and hands out runs; the reader walks through a
+ * run's blocks without further look-ups in caches, and bytes of consecutive blocks are consecutive in the run's buffer.
  */
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -211,71 +212,72 @@ private:
     std::vector<Buffer> m_free;
 };
 
-/* ------------------------------------------------------------------------------------------------ block records */
-/** indexed_bzip2::BlockHeaderData / BlockData, BZ2BlockFetcher.hpp:18-34 */
-struct BlockHeaderData
+/* ------------------------------------------------------------------------------------------------ decoded runs */
+/** One block of a run: indexed_bzip2::BlockHeaderData / BlockData (BZ2BlockFetcher.hpp:18-34) without owning bytes. */
+struct BlockRecord
 {
-    size_t encodedOffsetInBits{ std::numeric_limits<size_t>::max() };
-    size_t encodedSizeInBits{ 0 };
-    uint32_t expectedCRC{ 0 };
-    bool isEndOfStreamBlock{ false };
-    bool isEndOfFile{ false };
-};
-
-struct BlockData : public BlockHeaderData
-{
-    std::shared_ptr<const uint8_t> buffer;   /* page-locked host copy of the whole batch output */
-    size_t dataOffset{ 0 };
-    size_t dataSize{ 0 };
-    size_t batchBytes{ 0 };                  /* decoded bytes that share `buffer` */
-    uint32_t calculatedCRC{ 0xFFFFFFFFu };
+    uint64_t bits{ 0 }, bitLength{ 0 };
+    uint64_t at{ 0 }, byteLength{ 0 };       /* the block's bytes inside the run's buffer */
+    uint32_t storedCrc{ 0 }, computedCrc{ 0xFFFFFFFFu };
     int status{ MI355X_BZ2_OK };
-
-    [[nodiscard]] const uint8_t* data() const { return buffer ? buffer.get() + dataOffset : nullptr; }
+    bool endOfStream{ false }, endOfFile{ false };
 };
 
-using BlockDataPtr = std::shared_ptr<BlockData>;
+/** Consecutive blocks [firstBlock, firstBlock + blocks.size()) of the finder's list, decoded by one batch. */
+struct DecodedRun
+{
+    size_t firstBlock{ 0 };
+    std::vector<BlockRecord> blocks;
+    std::shared_ptr<const uint8_t> bytes;    /* page-locked; block k at bytes + blocks[k].at */
+    size_t totalBytes{ 0 };
+    bool lookAhead{ false };                 /* launched ahead of the reader (not because a read was waiting for it) */
 
-/* ------------------------------------------------------------------------------------------------ GPU block fetcher */
-class GpuBlockFetcher
+    [[nodiscard]] size_t first() const { return firstBlock; }
+    [[nodiscard]] size_t count() const { return blocks.size(); }
+    [[nodiscard]] const BlockRecord& at( size_t block ) const { return blocks[block - firstBlock]; }
+};
+
+using RunPtr = std::shared_ptr<const DecodedRun>;
+
+/** Header fields of the block at a bit offset, parsed on the host (the GPU validates the rest when it decodes it). */
+struct BlockHeader
+{
+    uint64_t bits{ 0 }, bitLength{ 0 };
+    uint32_t storedCrc{ 0 };
+    bool endOfStream{ false }, endOfFile{ false };
+};
+
+/* ------------------------------------------------------------------------------------------------ batch scheduler */
+class BatchScheduler
 {
 public:
-    GpuBlockFetcher( std::shared_ptr<Source> source, std::shared_ptr<BlockFinder> finder,
-                     size_t parallelization, int device ) :
+    BatchScheduler( std::shared_ptr<Source> source, std::shared_ptr<BlockFinder> finder, size_t parallelization, int device ) :
         m_source( std::move( source ) ),
-        m_blockFinder( std::move( finder ) ),
-        m_parallelization( std::max<size_t>( 1, parallelization ) ),
-        m_cache( std::max<size_t>( 16, m_parallelization ) ),              /* BlockFetcher.hpp:180 */
-        /* BlockFetcher.hpp:181-182 use 2 P.  The prefetch window (= this capacity) bounds decoded-but-unread blocks plus
-         * blocks in flight; with 2 P a second full batch could only start once the reader had consumed all of the first,
-         * so launches went out with P / 2 blocks each (80 ms latency floor per launch: 5 GB/s at P = 512).  (contexts + 2) P
-         * lets every context have a full batch in flight while another one is being read. */
-        m_prefetchCache( ( contextCount( m_parallelization ) + 2 ) * m_parallelization ),
-        m_failedPrefetchCache( ( contextCount( m_parallelization ) + 2 ) * m_parallelization )
+        m_finder( std::move( finder ) ),
+        m_batch( std::max<size_t>( 1, parallelization ) ),
+        m_contexts( contextCount( m_batch ) ),
+        /* blocks that may be decoded ahead of the reader, finished or in flight: every context a full batch in flight
+         * while another one is being read */
+        m_window( ( m_contexts + 2 ) * m_batch ),
+        m_ready( m_window + std::max<size_t>( 16, m_batch ) )
     {
-        /* BZ2BlockFetcher ctor reads the stream header once: BZ2BlockFetcher.hpp:56 */
+        /* BZ2BlockFetcher's constructor reads the stream header once: BZ2BlockFetcher.hpp:56 */
         if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), 0 ) == 0 ) {
             fail( MI355X_BZ2_ERR_STREAM_HEADER );
         }
-        /* Several decoder contexts, each with its own submission thread, once batches are large enough to be worth it:
-         * while one batch is copied to the host (and consumed), the next ones are already being decoded.  A batch has a
-         * latency floor of ~80 ms (one wave per block in the Huffman stage), so smaller batches want more of them in
-         * flight: three contexts up to P = 640 (20 GB of scratch at the default P = 512), two above.  Small P keeps two so that
-         * an on-demand block does not have to wait for a prefetch launch (see get()); P = 1 is the serial reader. */
-        const size_t nContexts = contextCount( m_parallelization );
-        const auto tCtor = std::chrono::steady_clock::now();
-        for ( size_t i = 0; i < nContexts; ++i ) {
+        /* Several decoder contexts, each with its own submission thread: while one batch is copied to the host (and
+         * consumed), the next ones are being decoded.  They share ONE resident copy of the compressed file. */
+        const auto tCreate = std::chrono::steady_clock::now();
+        for ( size_t i = 0; i < m_contexts; ++i ) {
             mi355x_bz2_config config{};
             config.device = device;
-            /* scratch (13 MB per block, ~35 ms per GB to allocate) grows with the batches that are really launched: a
-             * reader that seeks and reads a little never pays for P blocks, a sequential one pays once per context, on
-             * that context's own thread */
-            config.max_batch_blocks = (uint32_t)std::min<size_t>( m_parallelization, 64 );
+            /* scratch (13 MB per block) grows with the batches that are really launched: a reader that seeks and reads a
+             * little never pays for a full batch, a sequential one pays once per context, on that context's own thread */
+            config.max_batch_blocks = (uint32_t)std::min<size_t>( m_batch, 64 );
             mi355x_bz2_ctx* ctx = nullptr;
             int rc = mi355x_bz2_create( &config, &ctx );
             std::string detail;
             if ( rc == MI355X_BZ2_OK ) {
-                /* one resident copy of the compressed file for all contexts */
                 rc = m_ctxs.empty() ? mi355x_bz2_set_input_host( ctx, m_source->bytes(), m_source->size() )
                                     : mi355x_bz2_share_input( ctx, m_ctxs.front() );
                 if ( rc != MI355X_BZ2_OK ) {
@@ -290,34 +292,33 @@ public:
             }
             m_ctxs.push_back( ctx );
         }
-        /* The file is resident on the GPU now: let it find the block magics too (k_find_magic, a few ms per GB).  The
-         * host finder threads (ParallelBitStringFinder's job, ~1.3 GB/s of compressed data on eight cores) would
-         * otherwise pace the whole reader.  Same offsets, delivered at once; if the scan cannot be used (more matches
-         * than its result buffer holds) the host threads take over as before. */
+        /* The file is resident on the GPU now: let it find the block magics too (k_find_magic, a few ms per GB); the
+         * host finder threads (about 1.3 GB/s of compressed data on eight cores) would pace the whole reader.  Same
+         * offsets, delivered at once; if the scan cannot be used (more matches than its result buffer holds) the host
+         * threads take over. */
         const auto tInput = std::chrono::steady_clock::now();
-        if ( !m_blockFinder->finalized() ) {
-            /* the scan keeps up to 2^20 matches (>= 100 GB of level-9 data) and reports MI355X_BZ2_ERR_OUTPUT_CAPACITY beyond */
+        if ( !m_finder->finalized() ) {
             std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
             uint64_t found = 0;
             if ( ( mi355x_bz2_find_magic_device( m_ctxs.front(), MI355X_BZ2_MAGIC_BLOCK, offsets.data(), offsets.size(),
                                                  &found ) == MI355X_BZ2_OK ) && ( found <= offsets.size() ) ) {
                 offsets.resize( found );
-                m_blockFinder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
+                m_finder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
             }
         }
         if ( m_trace ) {
             const auto now = std::chrono::steady_clock::now();
             std::fprintf( stderr, "[reader] %zu contexts + %.0f MB resident: %.1f ms, magic scan: %.1f ms (%zu blocks)\n",
                           m_ctxs.size(), m_source->size() / 1e6,
-                          std::chrono::duration<double, std::milli>( tInput - tCtor ).count(),
-                          std::chrono::duration<double, std::milli>( now - tInput ).count(), m_blockFinder->size() );
+                          std::chrono::duration<double, std::milli>( tInput - tCreate ).count(),
+                          std::chrono::duration<double, std::milli>( now - tInput ).count(), m_finder->size() );
         }
         for ( auto* const ctx : m_ctxs ) {
             m_workers.emplace_back( [this, ctx] () { workerMain( ctx ); } );
         }
     }
 
-    ~GpuBlockFetcher()
+    ~BatchScheduler()
     {
         {
             const std::scoped_lock lock( m_queueMutex );
@@ -327,318 +328,285 @@ public:
         for ( auto& worker : m_workers ) {
             if ( worker.joinable() ) worker.join();
         }
-        m_prefetching.clear();
+        m_flights.clear();
         for ( auto it = m_ctxs.rbegin(); it != m_ctxs.rend(); ++it ) mi355x_bz2_destroy( *it );   /* owner of the input last */
     }
 
+    /** Decoder contexts for a batch size: a batch has a latency floor (its largest block), so smaller batches want more
+     * of them in flight: three contexts up to 640 blocks per batch, two above; small batches keep two so that a block
+     * someone waits for does not queue behind a look-ahead launch; one block at a time is the serial reader. */
     [[nodiscard]] static size_t
-    contextCount( size_t parallelization )
+    contextCount( size_t batch )
     {
         if ( const char* const forced = std::getenv( "MI355X_BZ2_READER_CONTEXTS" ) ) {
             return std::min<size_t>( 4, std::max<size_t>( 1, std::strtoul( forced, nullptr, 10 ) ) );
         }
-        return parallelization >= 64 ? ( parallelization <= 640 ? 3 : 2 ) : ( parallelization >= 2 ? 2 : 1 );
+        return batch >= 64 ? ( batch <= 640 ? 3 : 2 ) : ( batch >= 2 ? 2 : 1 );
     }
 
-    /** BZ2BlockFetcher::readBlockHeader, BZ2BlockFetcher.hpp:64-82, for the EOS / next-stream probe on the caller
-     * thread.  Host-side parse of magic, CRC, randomised bit and origPtr (bzip2.hpp:479-519); the tree section of a
-     * data block is validated when that block is decoded on the GPU. */
-    [[nodiscard]] BlockHeaderData
-    readBlockHeader( size_t blockOffset ) const
+    /** The fields in front of a block's tables (bzip2.hpp:479-519), read on the caller's thread: what the reader needs to
+     * recognise an end-of-stream block behind a data block.  Throws like the reference's block constructor would. */
+    [[nodiscard]] BlockHeader
+    peekHeader( uint64_t bits ) const
     {
-        BlockHeaderData result;
-        result.encodedOffsetInBits = blockOffset;
-        uint64_t pos = blockOffset;
-        bool eof = blockOffset > m_source->sizeInBits();
-        const uint64_t hi = readBits( *m_source, pos, 24, eof );
-        const uint64_t lo = readBits( *m_source, pos, 24, eof );
-        result.expectedCRC = readBits( *m_source, pos, 32, eof );
+        BlockHeader header;
+        header.bits = bits;
+        uint64_t pos = bits;
+        bool eof = bits > m_source->sizeInBits();
+        const uint64_t magic = ( (uint64_t)readBits( *m_source, pos, 24, eof ) << 24 ) | readBits( *m_source, pos, 24, eof );
+        header.storedCrc = readBits( *m_source, pos, 32, eof );
         if ( eof ) fail( MI355X_BZ2_ERR_EOF );
-        const uint64_t magic = ( hi << 24 ) | lo;
         if ( magic == MI355X_BZ2_MAGIC_EOS ) {
-            result.isEndOfStreamBlock = true;
+            header.endOfStream = true;
             if ( ( pos & 7 ) != 0 ) {
-                readBits( *m_source, pos, 8 - (unsigned)( pos & 7 ), eof );
+                readBits( *m_source, pos, 8 - (unsigned)( pos & 7 ), eof );   /* padding to the next byte */
                 if ( eof ) fail( MI355X_BZ2_ERR_EOF );
             }
-            result.encodedSizeInBits = pos - blockOffset;
-            result.isEndOfFile = pos >= m_source->sizeInBits();
-            return result;
+            header.bitLength = pos - bits;
+            header.endOfFile = pos >= m_source->sizeInBits();
+            return header;
         }
         if ( magic != MI355X_BZ2_MAGIC_BLOCK ) {
-            char buffer[96];
-            std::snprintf( buffer, sizeof( buffer ), "0x%llx at bit offset %llu", (unsigned long long)magic,
-                           (unsigned long long)blockOffset );
-            fail( MI355X_BZ2_ERR_BAD_MAGIC, buffer );
+            char text[96];
+            std::snprintf( text, sizeof( text ), "0x%llx at bit offset %llu", (unsigned long long)magic, (unsigned long long)bits );
+            fail( MI355X_BZ2_ERR_BAD_MAGIC, text );
         }
-        const uint32_t randomized = readBits( *m_source, pos, 1, eof );
+        const bool randomised = readBits( *m_source, pos, 1, eof ) != 0;
         if ( eof ) fail( MI355X_BZ2_ERR_EOF );
-        if ( randomized != 0 ) fail( MI355X_BZ2_ERR_RANDOMIZED );
+        if ( randomised ) fail( MI355X_BZ2_ERR_RANDOMIZED );
         const uint32_t origPtr = readBits( *m_source, pos, 24, eof );
         if ( eof ) fail( MI355X_BZ2_ERR_EOF );
         if ( origPtr > 900000 ) fail( MI355X_BZ2_ERR_ORIGPTR_RANGE );
-        return result;
+        return header;
     }
 
-    /** BlockFetcher::get, BlockFetcher.hpp:244-317 */
-    [[nodiscard]] BlockDataPtr
-    get( size_t blockOffset, std::optional<size_t> dataBlockIndex = std::nullopt )
+    /**
+     * The run that holds block number `block` of the finder's list -- from the finished runs, from a launch in flight, or
+     * from a launch of its own that goes ahead of everything queued.  Along the way: the access is noted, finished
+     * launches are collected, and the range of blocks that the access pattern makes worth decoding ahead is launched.
+     * A block's own failure is NOT an error here: it is in its record, for the read that needs the block.
+     */
+    [[nodiscard]] RunPtr
+    demand( size_t block )
     {
-        const auto tStart = std::chrono::steady_clock::now();
         ++m_stats.gets;
+        collectFinished();
+        m_pattern.note( block );
+        if ( m_pattern.inOrder() ) {
+            m_ready.dropBefore( block );      /* a sequential reader never comes back (BlockFetcher.hpp:343-346) */
+        }
 
-        /* getFromCaches, BlockFetcher.hpp:369-391 */
-        std::shared_future<BlockDataPtr> queued;
-        std::optional<BlockDataPtr> cached;
-        if ( const auto match = m_prefetching.find( blockOffset ); match != m_prefetching.end() ) {
-            queued = match->second;
-            m_prefetching.erase( match );
+        std::shared_future<RunPtr> pending;
+        RunPtr run = m_ready.find( block );
+        if ( run ) {
+            ++( run->lookAhead ? m_stats.prefetch_hits : m_stats.cache_hits );
+        } else if ( const auto flight = flightOf( block ); flight != m_flights.end() ) {
+            pending = flight->second.result;
             ++m_stats.prefetch_hits;
         } else {
-            cached = m_cache.get( blockOffset );
-            if ( cached ) {
-                ++m_stats.cache_hits;
-            } else {
-                cached = m_prefetchCache.get( blockOffset );
-                if ( cached ) {
-                    ++m_stats.prefetch_hits;
-                    m_prefetchCache.evict( blockOffset );
-                    insertIntoCache( blockOffset, *cached );
-                }
-            }
-        }
-
-        const auto validDataBlockIndex = dataBlockIndex ? *dataBlockIndex : m_blockFinder->find( blockOffset );
-
-        std::vector<uint64_t> batch;
-        const bool onDemand = !cached.has_value() && !queued.valid();
-        if ( onDemand ) {
+            /* A batch returns when its slowest block is through: the block somebody waits for goes alone, ahead of
+             * everything queued, and what should follow it as a second launch on another context. */
             ++m_stats.on_demand_fetches;
-            batch.push_back( blockOffset );
+            pending = launch( block, 1, /* urgent */ true, /* lookAhead */ false );
         }
+        launchAhead( block, /* somebodyWaits */ pending.valid() );
 
-        m_fetchingStrategy.fetch( validDataBlockIndex );
-        collectPrefetches( batch, onDemand, blockOffset );
-
-        if ( onDemand && ( batch.size() > 1 ) && ( m_ctxs.size() >= 2 ) ) {
-            /* A batch returns when its slowest block is through (an incompressible block takes 68 ms, a text block
-             * 24 ms): the block the caller is waiting for goes alone, ahead of everything queued, and its prefetch
-             * companions as a second launch on another context. */
-            queued = submitBatch( { batch[0] }, /* urgent */ true )[0];
-            const std::vector<uint64_t> companions( batch.begin() + 1, batch.end() );
-            const auto futures = submitBatch( companions );
-            for ( size_t i = 0; i < companions.size(); ++i ) {
-                m_prefetching.emplace( companions[i], futures[i] );
-                ++m_stats.prefetches_submitted;
+        if ( !run ) {
+            const auto tWait = std::chrono::steady_clock::now();
+            run = pending.get();
+            m_stats.wait_seconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - tWait ).count();
+            if ( !run ) {
+                const std::scoped_lock lock( m_queueMutex );
+                fail( MI355X_BZ2_ERR_DEVICE, m_workerError );
             }
-        } else if ( !batch.empty() ) {
-            auto futures = submitBatch( batch, onDemand );
-            size_t first = 0;
-            if ( onDemand ) {
-                queued = futures[0];
-                first = 1;
-            }
-            for ( size_t i = first; i < batch.size(); ++i ) {
-                m_prefetching.emplace( batch[i], futures[i] );
-                ++m_stats.prefetches_submitted;
-            }
+            collectFinished();
         }
-
-        if ( cached.has_value() ) {
-            return *cached;
-        }
-
-        const auto tWait = std::chrono::steady_clock::now();
-        auto result = queued.get();
-        m_stats.wait_seconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - tWait ).count();
-        if ( !result ) {
-            fail( MI355X_BZ2_ERR_DEVICE, m_workerError );
-        }
-        if ( result->status != MI355X_BZ2_OK ) {
-            /* on-demand failures surface to the caller (BlockFetcher.hpp:305) */
-            fail( result->status, "block at bit offset " + std::to_string( blockOffset ) );
-        }
-        insertIntoCache( blockOffset, result );
-        (void)tStart;
-        return result;
+        return run;
     }
 
     [[nodiscard]] mi355x_bz2_reader_stats
     statistics() const
     {
         auto result = m_stats;
-        {
-            const std::scoped_lock lock( m_queueMutex );
-            result.batches = m_batches;
-            result.blocks_decoded = m_blocksDecoded;
-            result.decode_seconds = m_decodeSeconds;
-        }
+        const std::scoped_lock lock( m_queueMutex );
+        result.batches = m_batches;
+        result.blocks_decoded = m_blocksDecoded;
+        result.decode_seconds = m_decodeSeconds;
         return result;
     }
 
 private:
-    struct Request
+    struct Launch
     {
+        size_t first{ 0 };
         std::vector<uint64_t> offsets;
-        std::vector<std::promise<BlockDataPtr> > promises;
-        std::shared_ptr<std::atomic<bool> > done;   /* set after the last promise: the futures of a batch become ready together */
-    };
-
-    struct BatchInFlight
-    {
+        bool lookAhead{ false };
+        std::promise<RunPtr> promise;
         std::shared_ptr<std::atomic<bool> > done;
-        std::vector<uint64_t> offsets;
     };
 
-    void
-    insertIntoCache( size_t blockOffset, BlockDataPtr blockData )
+    struct Flight
     {
-        if ( m_fetchingStrategy.isSequential() ) {
-            m_cache.clear();   /* BlockFetcher.hpp:343-346 */
-        } else if ( blockData && blockData->buffer
-                    && ( blockData->batchBytes > 8 * std::max<size_t>( blockData->dataSize, size_t( 1 ) << 20 ) ) ) {
-            /* A block shares the page-locked buffer of its whole batch.  This cache survives random access for a long
-             * time: one kept block must not hold hundreds of MB of a batch whose other blocks are long gone. */
-            auto own = std::make_shared<BlockData>( *blockData );
-            std::shared_ptr<uint8_t> bytes( new uint8_t[std::max<size_t>( own->dataSize, 1 )], std::default_delete<uint8_t[]>() );
-            std::memcpy( bytes.get(), blockData->data(), own->dataSize );
-            own->buffer = std::move( bytes );
-            own->dataOffset = 0;
-            own->batchBytes = own->dataSize;
-            blockData = std::move( own );
-        }
-        m_cache.insert( blockOffset, std::move( blockData ) );
+        size_t count{ 0 };
+        std::shared_future<RunPtr> result;
+        std::shared_ptr<std::atomic<bool> > done;
+    };
+
+    using Flights = std::map<size_t, Flight>;   /* by first block */
+
+    [[nodiscard]] Flights::iterator
+    flightOf( size_t block )
+    {
+        auto behind = m_flights.upper_bound( block );
+        if ( behind == m_flights.begin() ) return m_flights.end();
+        --behind;
+        return block - behind->first < behind->second.count ? behind : m_flights.end();
     }
 
-    [[nodiscard]] bool
-    isInCacheOrQueue( size_t blockOffset ) const
-    {
-        return ( m_prefetching.find( blockOffset ) != m_prefetching.end() )
-               || m_cache.test( blockOffset ) || m_prefetchCache.test( blockOffset );
-    }
-
-    /** processReadyPrefetches, BlockFetcher.hpp:414-438.  The reference polls every future; here all futures of a batch
-     * become ready together, so one flag per batch is polled (a get() with 5 000 blocks in flight must not cost 5 000
-     * future look-ups: that alone capped the reader at 5 GB/s). */
+    /** Launches whose worker is through move to the finished runs (one flag per launch is polled, not one future per
+     * block: thousands of blocks can be in flight). */
     void
-    processReadyPrefetches()
+    collectFinished()
     {
-        for ( auto batch = m_batchesInFlight.begin(); batch != m_batchesInFlight.end(); ) {
-            if ( !batch->done->load( std::memory_order_acquire ) ) {
-                ++batch;
+        for ( auto flight = m_flights.begin(); flight != m_flights.end(); ) {
+            if ( !flight->second.done->load( std::memory_order_acquire ) ) {
+                ++flight;
                 continue;
             }
-            for ( const auto offset : batch->offsets ) {
-                const auto it = m_prefetching.find( offset );
-                if ( it == m_prefetching.end() ) continue;     /* fetched on demand meanwhile */
-                const auto result = it->second.get();
-                if ( result && ( result->status == MI355X_BZ2_OK ) ) {
-                    m_prefetchCache.insert( it->first, result );
-                } else {
-                    /* Prefetching failed: ignore result and error; it is retried (and reported) on demand. */
-                    m_failedPrefetchCache.insert( it->first, true );
-                    ++m_stats.failed_prefetches;
+            if ( const auto run = flight->second.result.get() ) {
+                if ( run->lookAhead ) {
+                    for ( const auto& record : run->blocks ) {
+                        m_stats.failed_prefetches += record.status != MI355X_BZ2_OK ? 1 : 0;
+                    }
                 }
-                m_prefetching.erase( it );
+                m_ready.insert( run );
+                m_inFlightBlocks -= flight->second.count;
+                flight = m_flights.erase( flight );
+            } else {
+                ++flight;   /* device failure: stays, and fails whoever asks for it */
             }
-            batch = m_batchesInFlight.erase( batch );
         }
     }
 
-    /** prefetchNewBlocks, BlockFetcher.hpp:446-559, batch-oriented. */
+    /** Decide from the access pattern which blocks behind `block` to decode ahead, and launch them as ONE contiguous
+     * range if that is worth a launch. */
     void
-    collectPrefetches( std::vector<uint64_t>& batch, bool onDemand, size_t requestedOffset )
+    launchAhead( size_t block, bool somebodyWaits )
     {
-        processReadyPrefetches();
-        /* threadPoolSaturated, BlockFetcher.hpp:453-460: one batch of up to P blocks per decoder context */
-        const auto inFlight = m_prefetching.size() + ( onDemand ? 1 : 0 );
-        const size_t limit = m_parallelization * m_ctxs.size();
-        if ( inFlight >= limit ) return;
-        /* The candidate search below looks at up to 2 P indexes.  While a launch is held back for want of candidates
-         * (see the batching rule at the end) a sequential reader gains about one candidate per get(): searching again
-         * on every call would cost O(P^2) per batch (1 s per 2 560 blocks), so the search is skipped for a while. */
-        if ( !onDemand && ( m_skipCollect > 0 ) && !m_prefetching.empty() ) {
-            --m_skipCollect;
+        const size_t limit = m_batch * m_ctxs.size();        /* one full batch per context in flight */
+        if ( m_inFlightBlocks >= limit ) return;
+        /* While a launch is held back for want of blocks (rule at the end) a sequential reader gains about one candidate
+         * per call: looking again on every call would cost O(batch^2) per batch. */
+        if ( !somebodyWaits && ( m_holdOff > 0 ) && !m_flights.empty() ) {
+            --m_holdOff;
             return;
         }
-        const size_t room = std::min( limit - inFlight, m_parallelization );
-
-        const auto indexes = m_fetchingStrategy.prefetch( m_prefetchCache.capacity() );
-        std::vector<uint64_t> candidates;
-        for ( const auto index : indexes ) {
-            if ( candidates.size() >= room ) break;
-            if ( m_blockFinder->finalized() && ( index >= m_blockFinder->size() ) ) continue;
-            const auto [offset, code] = m_blockFinder->get( index, /* timeout */ 0 );
-            if ( !offset ) continue;
-            if ( *offset == requestedOffset || isInCacheOrQueue( *offset ) || m_failedPrefetchCache.test( *offset ) ) {
-                m_prefetchCache.touch( *offset );
-                m_cache.touch( *offset );
-                continue;
-            }
-            /* Avoid cache pollution: stop when results that are still wanted would be evicted (BlockFetcher.hpp:527-535) */
-            if ( m_prefetching.size() + candidates.size() + 1 > m_prefetchCache.capacity() ) break;
-            candidates.push_back( *offset );
+        const auto wanted = m_pattern.ahead( m_window );
+        if ( wanted.count == 0 ) return;
+        size_t end = wanted.first + wanted.count;
+        if ( m_finder->finalized() ) end = std::min( end, m_finder->size() );
+        /* the first block of the range that is neither finished nor in flight */
+        size_t from = wanted.first;
+        for ( ;; ) {
+            from = m_ready.firstGap( from );
+            const auto flight = flightOf( from );
+            if ( flight == m_flights.end() ) break;
+            from = flight->first + flight->second.count;
         }
-        if ( candidates.empty() ) {
-            m_skipCollect = std::max<size_t>( 1, m_parallelization / 8 );
+        if ( from >= end ) {
+            m_holdOff = std::max<size_t>( 1, m_batch / 8 );
             return;
         }
-        /* GPU batching rule: piggy-back on an on-demand launch, otherwise wait until at least P/2 blocks can go in one
-         * launch (or nothing is in flight at all). */
-        const size_t batchMin = std::max<size_t>( 1, m_parallelization / 2 );
-        if ( onDemand || ( candidates.size() >= batchMin ) || m_prefetching.empty() ) {
-            batch.insert( batch.end(), candidates.begin(), candidates.end() );
-            m_skipCollect = 0;
+        /* as many as fit: a batch, the room in flight, the window of blocks decoded ahead (finished ones that are still
+         * wanted must not be pushed out by newer ones, BlockFetcher.hpp:527-535) */
+        size_t room = std::min( { m_batch, limit - m_inFlightBlocks, end - from } );
+        const size_t ahead = m_ready.blocksWithin( wanted.first, end ) + m_inFlightBlocks;
+        room = ahead >= m_window ? 0 : std::min( room, m_window - ahead );
+        std::vector<uint64_t> offsets;
+        for ( size_t b = from; b < from + room; ++b ) {
+            if ( m_ready.covers( b ) || ( flightOf( b ) != m_flights.end() ) ) break;
+            const auto [offset, code] = m_finder->get( b, /* do not wait */ 0 );
+            if ( !offset ) break;
+            offsets.push_back( *offset );
+        }
+        if ( offsets.empty() ) {
+            m_holdOff = std::max<size_t>( 1, m_batch / 8 );
+            return;
+        }
+        /* A launch has a latency floor: go along with a launch somebody waits for, otherwise wait until half a batch
+         * can go at once -- unless nothing is in flight at all. */
+        const size_t worthIt = std::max<size_t>( 1, m_batch / 2 );
+        if ( somebodyWaits || ( offsets.size() >= worthIt ) || m_flights.empty() ) {
+            m_stats.prefetches_submitted += offsets.size();
+            launch( from, std::move( offsets ), /* urgent */ false, /* lookAhead */ true );
+            m_holdOff = 0;
         } else {
-            m_skipCollect = std::min( batchMin - candidates.size(), std::max<size_t>( 1, m_parallelization / 8 ) );
+            m_holdOff = std::min( worthIt - offsets.size(), std::max<size_t>( 1, m_batch / 8 ) );
         }
     }
 
-    [[nodiscard]] std::vector<std::shared_future<BlockDataPtr> >
-    submitBatch( const std::vector<uint64_t>& offsets, bool urgent = false )
+    std::shared_future<RunPtr>
+    launch( size_t first, size_t count, bool urgent, bool lookAhead )
     {
-        auto request = std::make_unique<Request>();
-        request->offsets = offsets;
-        request->promises.resize( offsets.size() );
-        request->done = std::make_shared<std::atomic<bool> >( false );
-        m_batchesInFlight.push_back( BatchInFlight{ request->done, offsets } );
-        std::vector<std::shared_future<BlockDataPtr> > futures;
-        futures.reserve( offsets.size() );
-        for ( auto& promise : request->promises ) {
-            futures.emplace_back( promise.get_future().share() );
+        std::vector<uint64_t> offsets;
+        for ( size_t b = first; b < first + count; ++b ) {
+            const auto [offset, code] = m_finder->get( b );
+            if ( !offset ) {
+                fail( MI355X_BZ2_ERR_LOGIC, "block " + std::to_string( b ) + " is not in the block finder's list" );
+            }
+            offsets.push_back( *offset );
         }
+        return launch( first, std::move( offsets ), urgent, lookAhead );
+    }
+
+    std::shared_future<RunPtr>
+    launch( size_t first, std::vector<uint64_t> offsets, bool urgent, bool lookAhead )
+    {
+        auto work = std::make_unique<Launch>();
+        work->first = first;
+        work->offsets = std::move( offsets );
+        work->lookAhead = lookAhead;
+        work->done = std::make_shared<std::atomic<bool> >( false );
+        Flight flight;
+        flight.count = work->offsets.size();
+        flight.result = work->promise.get_future().share();
+        flight.done = work->done;
+        m_inFlightBlocks += flight.count;
+        const auto result = flight.result;
+        m_flights.emplace( first, std::move( flight ) );
         {
             const std::scoped_lock lock( m_queueMutex );
             if ( urgent ) {
-                m_queue.push_front( std::move( request ) );   /* someone is waiting for it */
+                m_queue.push_front( std::move( work ) );   /* someone is waiting for it */
             } else {
-                m_queue.push_back( std::move( request ) );
+                m_queue.push_back( std::move( work ) );
             }
             m_queueChanged.notify_all();
         }
-        return futures;
+        return result;
     }
 
-    /** The single GPU submission thread: replaces ThreadPool workers calling decodeBlock (BlockFetcher.hpp:620-642). */
+    /** One submission thread per decoder context: takes a launch, decodes the batch, copies it to a page-locked buffer,
+     * publishes the run.  Replaces the thread pool of per-block tasks (BlockFetcher.hpp:620-642). */
     void
     workerMain( mi355x_bz2_ctx* const ctx )
     {
         while ( true ) {
-            std::unique_ptr<Request> request;
+            std::unique_ptr<Launch> work;
             {
                 std::unique_lock lock( m_queueMutex );
                 m_queueChanged.wait( lock, [this] { return m_stop || !m_queue.empty(); } );
                 if ( m_queue.empty() ) {
                     return;   /* m_stop */
                 }
-                request = std::move( m_queue.front() );
+                work = std::move( m_queue.front() );
                 m_queue.pop_front();
             }
             const auto t0 = std::chrono::steady_clock::now();
-            const auto n = (uint32_t)request->offsets.size();
+            const auto n = (uint32_t)work->offsets.size();
             std::vector<mi355x_bz2_block_result> results( n );
             uint64_t total = 0;
-            int rc = mi355x_bz2_decode_batch( ctx, request->offsets.data(), n, results.data(), &total );
+            int rc = mi355x_bz2_decode_batch( ctx, work->offsets.data(), n, results.data(), &total );
             const auto t1 = std::chrono::steady_clock::now();
             auto t2 = t1;
             std::shared_ptr<const uint8_t> buffer;
@@ -654,40 +622,42 @@ private:
             if ( m_trace ) {
                 const auto ms = [] ( auto a, auto b ) { return std::chrono::duration<double, std::milli>( b - a ).count(); };
                 const auto t3 = std::chrono::steady_clock::now();
-                std::fprintf( stderr, "[reader] t=%.1f ms: batch of %u blocks on ctx %p: decode %.1f ms, host buffer %.1f ms, "
-                              "copy of %.0f MB %.1f ms\n", ms( m_created, t0 ), n, (void*)ctx, ms( t0, t1 ), ms( t1, t2 ),
-                              total / 1e6, ms( t2, t3 ) );
+                std::fprintf( stderr, "[reader] t=%.1f ms: blocks [%zu, +%u) on ctx %p: decode %.1f ms, host buffer %.1f ms, "
+                              "copy of %.0f MB %.1f ms\n", ms( m_created, t0 ), work->first, n, (void*)ctx, ms( t0, t1 ),
+                              ms( t1, t2 ), total / 1e6, ms( t2, t3 ) );
             }
             if ( rc != MI355X_BZ2_OK ) {
                 {
                     const std::scoped_lock lock( m_queueMutex );
                     m_workerError = mi355x_bz2_last_error( ctx );
                 }
-                for ( auto& promise : request->promises ) {
-                    promise.set_value( nullptr );
-                }
-                request->done->store( true, std::memory_order_release );
+                work->promise.set_value( nullptr );
+                work->done->store( true, std::memory_order_release );
                 continue;
             }
+            auto run = std::make_shared<DecodedRun>();
+            run->firstBlock = work->first;
+            run->bytes = std::move( buffer );
+            run->totalBytes = total;
+            run->lookAhead = work->lookAhead;
+            run->blocks.resize( n );
             for ( uint32_t i = 0; i < n; ++i ) {
                 const auto& r = results[i];
-                auto block = std::make_shared<BlockData>();
-                block->encodedOffsetInBits = request->offsets[i];
-                block->encodedSizeInBits = r.encoded_size_bits;
-                block->expectedCRC = r.header_crc;
-                block->calculatedCRC = r.computed_crc;
-                block->isEndOfStreamBlock = r.is_eos != 0;
-                block->isEndOfFile = r.is_eof != 0;
-                block->status = r.status;
+                auto& record = run->blocks[i];
+                record.bits = work->offsets[i];
+                record.bitLength = r.encoded_size_bits;
+                record.storedCrc = r.header_crc;
+                record.computedCrc = r.computed_crc;
+                record.endOfStream = r.is_eos != 0;
+                record.endOfFile = r.is_eof != 0;
+                record.status = r.status;
                 if ( r.status == MI355X_BZ2_OK ) {
-                    block->buffer = buffer;
-                    block->dataOffset = r.data_offset;
-                    block->dataSize = r.decoded_size;
-                    block->batchBytes = total;
+                    record.at = r.data_offset;
+                    record.byteLength = r.decoded_size;
                 }
-                request->promises[i].set_value( std::move( block ) );
             }
-            request->done->store( true, std::memory_order_release );
+            work->promise.set_value( std::move( run ) );
+            work->done->store( true, std::memory_order_release );
             const std::scoped_lock lock( m_queueMutex );
             ++m_batches;
             m_blocksDecoded += n;
@@ -697,23 +667,23 @@ private:
 
 private:
     const std::shared_ptr<Source> m_source;
-    const std::shared_ptr<BlockFinder> m_blockFinder;
-    const size_t m_parallelization;
+    const std::shared_ptr<BlockFinder> m_finder;
+    const size_t m_batch;        /* blocks per launch = the `parallelization` of the API */
+    const size_t m_contexts;
+    const size_t m_window;
 
-    FetchNextAdaptive m_fetchingStrategy;
-    LruCache<size_t, BlockDataPtr> m_cache;
-    LruCache<size_t, BlockDataPtr> m_prefetchCache;
-    LruCache<size_t, bool> m_failedPrefetchCache;
-    std::map<size_t, std::shared_future<BlockDataPtr> > m_prefetching;
-    std::list<BatchInFlight> m_batchesInFlight;
-    size_t m_skipCollect{ 0 };
+    SequentialityTracker m_pattern;
+    RunCache<DecodedRun> m_ready;
+    Flights m_flights;
+    size_t m_inFlightBlocks{ 0 };
+    size_t m_holdOff{ 0 };
 
     std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };
     std::vector<std::thread> m_workers;
     mutable std::mutex m_queueMutex;
     std::condition_variable m_queueChanged;
-    std::deque<std::unique_ptr<Request> > m_queue;
+    std::deque<std::unique_ptr<Launch> > m_queue;
     bool m_stop{ false };
     const bool m_trace{ std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr };
     const std::chrono::steady_clock::time_point m_created{ std::chrono::steady_clock::now() };
@@ -726,374 +696,346 @@ private:
 };
 
 /* ------------------------------------------------------------------------------------------------ the reader */
-class ParallelReader
+class StreamReader
 {
 public:
-    ParallelReader( std::shared_ptr<Source> source, size_t parallelization, int device ) :
+    /* parallelization 0: a batch of this many blocks keeps the GPU busy while a single cold read still returns after
+     * one small launch */
+    static constexpr size_t DEFAULT_BATCH = 512;
+
+    using Sink = std::function<void( const uint8_t*, uint64_t )>;
+    using OffsetMap = std::map<size_t, size_t>;
+
+    StreamReader( std::shared_ptr<Source> source, size_t parallelization, int device ) :
         m_source( std::move( source ) ),
-        m_parallelization( parallelization == 0 ? DEFAULT_PARALLELIZATION : parallelization ),
+        m_batch( parallelization == 0 ? DEFAULT_BATCH : parallelization ),
         m_device( device ),
-        m_verifyStreamCrc( parallelization == 1 )   /* the reference's serial reader checks, the parallel one does not */
+        m_checkStreamCrc( parallelization == 1 )   /* the reference's serial reader checks, the parallel one does not */
     {}
 
-    void setVerifyStreamCrc( bool enable ) { m_verifyStreamCrc = enable; }
+    void setVerifyStreamCrc( bool enable ) { m_checkStreamCrc = enable; }
     [[nodiscard]] uint64_t streamsVerified() const { return m_streamsVerified; }
 
-    /* parallelization 0: a batch of this many blocks keeps the GPU busy (6.5 GB/s at 640, 0.65 GB/s at 64) while a
-     * single cold read still returns after one batch of about 80 ms */
-    static constexpr size_t DEFAULT_PARALLELIZATION = 512;
-
     void
-    close()   /* ParallelBZ2Reader.hpp:104-111 */
+    close()
     {
-        m_blockFetcher.reset();
-        m_blockFinder.reset();
+        m_scheduler.reset();
+        m_finder.reset();
         m_source.reset();
     }
 
     [[nodiscard]] bool closed() const { return !m_source; }
-    [[nodiscard]] bool eof() const { return m_atEndOfFile; }
+    [[nodiscard]] bool eof() const { return m_atEnd; }
+
+    /** Decoded size, once the whole file has been seen (or an index was loaded). */
+    [[nodiscard]] std::optional<size_t>
+    size() const
+    {
+        if ( !m_index.sealed() ) return std::nullopt;
+        return (size_t)m_index.last().second;
+    }
 
     [[nodiscard]] size_t
-    tell() const   /* :129-142 */
+    tell() const
     {
-        if ( m_atEndOfFile ) {
-            const auto fileSize = size();
-            if ( !fileSize ) {
-                fail( MI355X_BZ2_ERR_LOGIC, "When the file end has been reached, the block map should have been "
-                                            "finalized and the file size should be available!" );
-            }
-            return *fileSize;
+        if ( !m_atEnd ) return m_position;
+        const auto total = size();
+        if ( !total ) {
+            fail( MI355X_BZ2_ERR_LOGIC, "at the end of the file its size has to be known" );
         }
-        return m_currentPosition;
+        return *total;
     }
 
-    [[nodiscard]] std::optional<size_t>
-    size() const   /* :144-151 */
-    {
-        if ( !m_blockMap.finalized() ) {
-            return std::nullopt;
-        }
-        return m_blockMap.back().second;
-    }
-
-    using WriteFunctor = std::function<void( const void*, uint64_t )>;
-
-    /** ParallelBZ2Reader::read, ParallelBZ2Reader.hpp:167-269 */
+    /**
+     * Up to `wanted` bytes from the current position into `sink` (an empty sink discards them).  Two things can happen
+     * per step: the position lies in a block the index knows -- then its run is fetched and the bytes go out; or it lies
+     * behind everything indexed -- then the next block of the file is decoded and indexed, which is where decode errors,
+     * end-of-stream blocks, stream CRCs and the end of the file come up.
+     */
     size_t
-    read( const WriteFunctor& writeFunctor, size_t nBytesToRead = std::numeric_limits<size_t>::max() )
+    read( const Sink& sink, size_t wanted = std::numeric_limits<size_t>::max() )
     {
         if ( closed() ) {
-            fail( MI355X_BZ2_ERR_CLOSED, "You may not call read on closed ParallelBZ2Reader!" );
+            fail( MI355X_BZ2_ERR_CLOSED, "read on a closed reader" );
         }
-        if ( eof() || ( nBytesToRead == 0 ) ) {
-            return 0;
+        size_t produced = 0;
+        while ( ( produced < wanted ) && !m_atEnd ) {
+            const auto span = m_index.locate( m_position );
+            if ( !span.covers( m_position ) ) {
+                if ( !indexNextBlock() ) {
+                    m_atEnd = true;
+                }
+                continue;
+            }
+            const auto run = scheduler().demand( finder().find( span.bits ) );
+            const auto& record = recordIn( *run, span.bits );
+            if ( record.status != MI355X_BZ2_OK ) {
+                fail( record.status, "block at bit offset " + std::to_string( span.bits ) );
+            }
+            const uint64_t inBlock = m_position - span.bytes;
+            if ( inBlock >= record.byteLength ) {
+                fail( MI355X_BZ2_ERR_LOGIC, "the block index promises more bytes than the block decodes to" );
+            }
+            const uint64_t piece = std::min<uint64_t>( record.byteLength - inBlock, wanted - produced );
+            if ( sink ) {
+                sink( run->bytes.get() + record.at + inBlock, piece );
+            }
+            produced += piece;
+            m_position += piece;
         }
-        size_t nBytesDecoded = 0;
-        while ( ( nBytesDecoded < nBytesToRead ) && !eof() ) {
-            BlockDataPtr blockData;
-            auto blockInfo = m_blockMap.findDataOffset( m_currentPosition );
-            if ( !blockInfo.contains( m_currentPosition ) ) {
-                /* Fetch new block for the first time and add information to block map. */
-                const auto dataBlockIndex = m_blockMap.dataBlockCount();
-                const auto encodedOffsetInBits = blockFinder().get( dataBlockIndex ).first;
-                if ( !encodedOffsetInBits ) {
-                    m_blockMap.finalize();
-                    m_atEndOfFile = true;
-                    break;
-                }
-                blockData = blockFetcher().get( *encodedOffsetInBits, dataBlockIndex );
-                m_blockMap.push( blockData->encodedOffsetInBits, blockData->encodedSizeInBits, blockData->dataSize );
-                /* BZ2Reader.hpp:481-484: new blocks arrive here in file order */
-                m_calculatedStreamCrc = ( ( m_calculatedStreamCrc << 1U ) | ( m_calculatedStreamCrc >> 31U ) )
-                                        ^ blockData->calculatedCRC;
-
-                /* EOS blocks have a different magic and are not found by the block finder (:204-238) */
-                if ( !blockData->isEndOfFile ) {
-                    const auto next = blockFetcher().readBlockHeader( blockData->encodedOffsetInBits
-                                                                      + blockData->encodedSizeInBits );
-                    if ( next.isEndOfStreamBlock ) {
-                        m_blockMap.push( next.encodedOffsetInBits, next.encodedSizeInBits, 0 );
-                        /* the end-of-stream block carries the CRC of the whole stream (BZ2Reader.hpp:406-416) */
-                        const auto calculated = m_calculatedStreamCrc;
-                        m_calculatedStreamCrc = 0;
-                        if ( m_verifyStreamCrc && m_streamCrcIntact ) {
-                            if ( next.expectedCRC != calculated ) {
-                                std::stringstream msg;
-                                msg << "[BZip2 block header] Stream CRC 0x" << std::hex << next.expectedCRC
-                                    << " does not match calculated CRC 0x" << calculated;
-                                fail( MI355X_BZ2_ERR_STREAM_CRC, msg.str() );
-                            }
-                            ++m_streamsVerified;
-                        }
-                        m_streamCrcIntact = true;
-                        const auto nextStreamOffsetInBits = next.encodedOffsetInBits + next.encodedSizeInBits;
-                        if ( nextStreamOffsetInBits < m_source->sizeInBits() ) {
-                            if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(),
-                                                                nextStreamOffsetInBits ) == 0 ) {
-                                std::cerr << "[Warning] Trailing garbage after EOF ignored!\n";
-                                m_blockFinder->finalize( m_blockMap.dataBlockCount() );
-                            }
-                        }
-                    }
-                }
-                blockInfo = m_blockMap.findDataOffset( m_currentPosition );
-                if ( !blockInfo.contains( m_currentPosition ) ) {
-                    continue;
-                }
-            } else {
-                blockData = blockFetcher().get( blockInfo.encodedOffsetInBits );
-            }
-
-            const auto offsetInBlock = m_currentPosition - blockInfo.decodedOffsetInBytes;
-            if ( offsetInBlock >= blockData->dataSize ) {
-                fail( MI355X_BZ2_ERR_LOGIC, "Block does not contain the requested offset even though it "
-                                            "shouldn't be according to block map!" );
-            }
-            const auto nBytesToDecode = std::min( blockData->dataSize - offsetInBlock, nBytesToRead - nBytesDecoded );
-            if ( writeFunctor ) {
-                writeFunctor( blockData->data() + offsetInBlock, nBytesToDecode );
-            }
-            nBytesDecoded += nBytesToDecode;
-            m_currentPosition += nBytesToDecode;
-        }
-        return nBytesDecoded;
+        return produced;
     }
 
-    /** BZ2ReaderInterface::read( fd, buffer, n ), BZ2ReaderInterface.hpp:35-57 + writeAll, FileUtils.hpp:803-826 */
+    /** read( fd, buffer, n ) of the interface: to a file descriptor and / or a buffer, or nowhere
+     * (BZ2ReaderInterface.hpp:35-57). */
     size_t
-    read( int outputFileDescriptor, char* outputBuffer, size_t nBytesToRead )
+    read( int outputFileDescriptor, char* outputBuffer, size_t wanted )
     {
         if ( ( outputFileDescriptor < 0 ) && ( outputBuffer == nullptr ) ) {
-            return read( WriteFunctor(), nBytesToRead );
+            return read( Sink(), wanted );
         }
-        uint64_t nBytesDecoded = 0;
-        const WriteFunctor writeFunctor = [&] ( const void* buffer, uint64_t size ) {
-            if ( outputFileDescriptor >= 0 ) {
-                const auto* p = static_cast<const uint8_t*>( buffer );
-                uint64_t written = 0;
-                while ( written < size ) {
-                    const auto n = ::write( outputFileDescriptor, p + written,
-                                            (size_t)std::min<uint64_t>( size - written, 1u << 30 ) );
-                    if ( n <= 0 ) {
-                        if ( n < 0 && errno == EINTR ) continue;
-                        fail( MI355X_BZ2_ERR_IO, std::string( "Failed to write all bytes because of: " ) + strerror( errno ) );
-                    }
+        uint64_t copied = 0;
+        return read( [&] ( const uint8_t* bytes, uint64_t size ) {
+            for ( uint64_t written = 0; ( outputFileDescriptor >= 0 ) && ( written < size ); ) {
+                const auto n = ::write( outputFileDescriptor, bytes + written, (size_t)std::min<uint64_t>( size - written, 1u << 30 ) );
+                if ( n > 0 ) {
                     written += (uint64_t)n;
+                } else if ( !( n < 0 && errno == EINTR ) ) {
+                    fail( MI355X_BZ2_ERR_IO, std::string( "write: " ) + strerror( errno ) );
                 }
             }
             if ( outputBuffer != nullptr ) {
-                std::memcpy( outputBuffer + nBytesDecoded, buffer, size );
+                std::memcpy( outputBuffer + copied, bytes, size );
             }
-            nBytesDecoded += size;
-        };
-        return read( writeFunctor, nBytesToRead );
+            copied += size;
+        }, wanted );
     }
 
-    /** ParallelBZ2Reader::seek, ParallelBZ2Reader.hpp:271-325 */
+    /** Seeking never decodes more than it has to: inside the indexed part of the file (or anywhere once the index is
+     * complete) only the position changes; a target behind the indexed part is reached by decoding forward. */
     size_t
-    seek( long long int offset, int origin )
+    seek( long long offset, int whence )
     {
         if ( closed() ) {
-            fail( MI355X_BZ2_ERR_CLOSED, "You may not call seek on closed ParallelBZ2Reader!" );
+            fail( MI355X_BZ2_ERR_CLOSED, "seek on a closed reader" );
         }
-        if ( origin == SEEK_END ) {
-            if ( !m_blockMap.finalized() ) {
-                read( WriteFunctor() );
-            }
+        if ( ( whence == SEEK_END ) && !m_index.sealed() ) {
+            read( Sink() );      /* the size is only known at the end */
         }
-        const auto positiveOffset = effectiveOffset( offset, origin );
-        if ( positiveOffset == tell() ) {
-            return positiveOffset;
+        long long target = offset;
+        if ( whence == SEEK_CUR ) {
+            target += (long long)tell();
+        } else if ( whence == SEEK_END ) {
+            target += (long long)size().value();
+        } else if ( whence != SEEK_SET ) {
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "invalid seek origin" );
         }
-        if ( positiveOffset < tell() ) {
-            m_atEndOfFile = false;
-            m_currentPosition = positiveOffset;
-            return positiveOffset;
+        target = std::max( target, 0LL );
+        if ( const auto total = size() ) {
+            target = std::min<long long>( target, (long long)*total );
         }
-        const auto blockInfo = m_blockMap.findDataOffset( positiveOffset );
-        if ( positiveOffset < blockInfo.decodedOffsetInBytes ) {
-            fail( MI355X_BZ2_ERR_LOGIC, "Block map returned unwanted block!" );
+        const auto goal = (size_t)target;
+        const size_t here = tell();
+        if ( goal == here ) {
+            return here;
         }
-        if ( blockInfo.contains( positiveOffset ) ) {
-            m_atEndOfFile = false;
-            m_currentPosition = positiveOffset;
-            return tell();
+        if ( ( goal < here ) || ( goal < m_index.frontier() ) ) {
+            m_position = goal;
+            m_atEnd = false;
+        } else if ( m_index.sealed() ) {
+            m_position = (size_t)m_index.last().second;
+            m_atEnd = true;
+        } else {
+            m_position = (size_t)m_index.frontier();
+            m_atEnd = false;
+            read( Sink(), goal - m_position );
         }
-        if ( m_blockMap.finalized() ) {
-            m_atEndOfFile = true;
-            m_currentPosition = m_blockMap.back().second;
-            return tell();
-        }
-        m_atEndOfFile = false;
-        m_currentPosition = blockInfo.decodedOffsetInBytes + blockInfo.decodedSizeInBytes;
-        read( WriteFunctor(), positiveOffset - tell() );
         return tell();
     }
 
-    [[nodiscard]] bool
-    blockOffsetsComplete() const
-    {
-        return m_blockMap.finalized();
-    }
+    [[nodiscard]] bool indexComplete() const { return m_index.sealed(); }
 
-    /** :339-350 */
-    [[nodiscard]] std::map<size_t, size_t>
+    [[nodiscard]] OffsetMap
     blockOffsets()
     {
-        if ( !m_blockMap.finalized() ) {
-            read( WriteFunctor() );
-            if ( !m_blockMap.finalized() || !blockFinder().finalized() ) {
-                fail( MI355X_BZ2_ERR_LOGIC, "Reading everything should have finalized the block map!" );
+        if ( !m_index.sealed() ) {
+            read( Sink() );
+            if ( !m_index.sealed() || !finder().finalized() ) {
+                fail( MI355X_BZ2_ERR_LOGIC, "the whole file was read but its block index is not complete" );
             }
         }
-        return m_blockMap.blockOffsets();
+        return availableBlockOffsets();
     }
 
-    [[nodiscard]] std::map<size_t, size_t>
+    [[nodiscard]] OffsetMap
     availableBlockOffsets() const
     {
-        return m_blockMap.blockOffsets();
+        const auto pairs = m_index.snapshot();
+        return { pairs.begin(), pairs.end() };
     }
 
-    /** :365-378 */
+    /** Import of a complete index: at least one block and the end-of-file entry.  Entries followed by an equal decoded
+     * offset are end-of-stream blocks and are not handed to the finder (ParallelBZ2Reader.hpp:365-378, 456-475). */
     void
-    setBlockOffsets( const std::map<size_t, size_t>& offsets )
+    setBlockOffsets( const OffsetMap& offsets )
     {
         if ( offsets.empty() ) {
-            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "May not clear offsets. Construct a new ParallelBZ2Reader instead!" );
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "an empty index cannot be loaded: open a new reader instead" );
         }
-        setBlockFinderOffsets( offsets );
+        handOffsetsToFinder( offsets );
         if ( offsets.size() < 2 ) {
-            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT,
-                  "Block offset map must contain at least one valid block and one EOS block!" );
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "an index needs at least one block and the end-of-file entry" );
         }
-        m_blockMap.setBlockOffsets( offsets );
+        m_index.assign( BlockIndex::Pairs( offsets.begin(), offsets.end() ) );
     }
 
-    /** :385-393 */
     [[nodiscard]] size_t
     tellCompressed() const
     {
-        const auto blockInfo = m_blockMap.findDataOffset( m_currentPosition );
-        if ( blockInfo.contains( m_currentPosition ) ) {
-            return blockInfo.encodedOffsetInBits;
-        }
-        return m_blockMap.empty() ? 0 : m_blockMap.back().first;
+        const auto span = m_index.locate( m_position );
+        if ( span.covers( m_position ) ) return (size_t)span.bits;
+        return m_index.empty() ? 0 : (size_t)m_index.last().first;
     }
 
-    /** :404-409 */
     void
     joinThreads()
     {
-        m_blockFetcher.reset();
-        m_blockFinder.reset();
+        m_scheduler.reset();
+        m_finder.reset();
     }
 
     [[nodiscard]] mi355x_bz2_reader_stats
     statistics() const
     {
-        return m_blockFetcher ? m_blockFetcher->statistics() : mi355x_bz2_reader_stats{};
+        return m_scheduler ? m_scheduler->statistics() : mi355x_bz2_reader_stats{};
     }
 
 private:
-    [[nodiscard]] size_t
-    effectiveOffset( long long int offset, int origin ) const
+    [[nodiscard]] static const BlockRecord&
+    recordIn( const DecodedRun& run, uint64_t bits )
     {
-        /* FileReader::effectiveOffset, src/core/filereader/FileReader.hpp:110-140 */
-        long long int base = 0;
-        switch ( origin ) {
-        case SEEK_SET: base = 0; break;
-        case SEEK_CUR: base = (long long int)tell(); break;
-        case SEEK_END:
-        {
-            const auto fileSize = size();
-            if ( !fileSize ) fail( MI355X_BZ2_ERR_LOGIC, "File size is not available to seek from end!" );
-            base = (long long int)*fileSize;
-            break;
+        const auto record = std::lower_bound( run.blocks.begin(), run.blocks.end(), bits,
+                                              [] ( const BlockRecord& r, uint64_t b ) { return r.bits < b; } );
+        if ( ( record == run.blocks.end() ) || ( record->bits != bits ) ) {
+            fail( MI355X_BZ2_ERR_LOGIC, "the decoded run does not hold the block it was fetched for" );
         }
-        default: fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "Invalid seek origin supplied" );
-        }
-        auto target = base + offset;
-        if ( target < 0 ) target = 0;
-        const auto fileSize = size();
-        if ( fileSize && ( (size_t)target > *fileSize ) ) {
-            target = (long long int)*fileSize;
-        }
-        return (size_t)target;
+        return *record;
     }
 
-    /** :412-433 */
+    /**
+     * Decodes the first block the index does not know yet and appends it -- together with the end-of-stream block behind
+     * it, if there is one (those have a magic of their own and are not in the finder's list).  False at the end of the
+     * file, where the index is sealed.  The stream CRC is folded over the blocks in this order (BZ2Reader.hpp:481-484).
+     */
+    bool
+    indexNextBlock()
+    {
+        const size_t number = m_index.dataBlocks();
+        const auto bits = finder().get( number ).first;
+        if ( !bits ) {
+            m_index.seal();
+            return false;
+        }
+        const auto run = scheduler().demand( number );
+        const auto& block = run->at( number );
+        if ( block.status != MI355X_BZ2_OK ) {
+            fail( block.status, "block at bit offset " + std::to_string( *bits ) );
+        }
+        m_index.append( block.bits, block.bitLength, block.byteLength );
+        m_streamCrc = ( ( m_streamCrc << 1U ) | ( m_streamCrc >> 31U ) ) ^ block.computedCrc;
+        if ( block.endOfFile ) {
+            return true;
+        }
+        const auto next = scheduler().peekHeader( block.bits + block.bitLength );
+        if ( !next.endOfStream ) {
+            return true;
+        }
+        m_index.append( next.bits, next.bitLength, 0 );
+        /* the end-of-stream block carries the CRC of the whole stream (BZ2Reader.hpp:406-416) */
+        const auto folded = std::exchange( m_streamCrc, 0U );
+        if ( m_checkStreamCrc ) {
+            if ( next.storedCrc != folded ) {
+                std::stringstream message;
+                message << "stream CRC 0x" << std::hex << next.storedCrc << " in the file, 0x" << folded << " calculated";
+                fail( MI355X_BZ2_ERR_STREAM_CRC, message.str() );
+            }
+            ++m_streamsVerified;
+        }
+        const uint64_t behind = next.bits + next.bitLength;
+        if ( ( behind < m_source->sizeInBits() )
+             && ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), behind ) == 0 ) ) {
+            std::cerr << "[Warning] Trailing garbage after EOF ignored!\n";
+            m_finder->finalize( m_index.dataBlocks() );   /* whatever the finder saw in the garbage is not a block */
+        }
+        return true;
+    }
+
     BlockFinder&
-    blockFinder()
+    finder()
     {
-        if ( m_blockFinder ) {
-            return *m_blockFinder;
-        }
-        const unsigned cores = std::max( 1u, std::thread::hardware_concurrency() );
-        /* look-ahead 3 * hardware_concurrency in the reference (BlockFinder.hpp:213); a GPU batch wants more */
-        const size_t lookAhead = std::max<size_t>( 3 * cores, 4 * m_parallelization );
-        m_blockFinder = std::make_shared<BlockFinder>( m_source->bytes(), m_source->size(), MI355X_BZ2_MAGIC_BLOCK,
-                                                       lookAhead, std::min( 8u, std::max( 1u, cores / 2 ) ) );
-        if ( m_blockMap.finalized() ) {
-            setBlockFinderOffsets( m_blockMap.blockOffsets() );
-        }
-        return *m_blockFinder;
-    }
-
-    /** :435-454 */
-    GpuBlockFetcher&
-    blockFetcher()
-    {
-        if ( m_blockFetcher ) {
-            return *m_blockFetcher;
-        }
-        (void)blockFinder();
-        m_blockFetcher = std::make_unique<GpuBlockFetcher>( m_source, m_blockFinder, m_parallelization, m_device );
-        if ( !blockFinder().finalized() ) {
-            blockFinder().startThreads();
-        }
-        return *m_blockFetcher;
-    }
-
-    /** :456-475 */
-    void
-    setBlockFinderOffsets( const std::map<size_t, size_t>& offsets )
-    {
-        if ( offsets.empty() ) {
-            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "A non-empty list of block offsets is required!" );
-        }
-        std::deque<size_t> encodedBlockOffsets;
-        for ( auto it = offsets.begin(), nit = std::next( offsets.begin() ); nit != offsets.end(); ++it, ++nit ) {
-            if ( it->second != nit->second ) {
-                encodedBlockOffsets.push_back( it->first );
+        if ( !m_finder ) {
+            const unsigned cores = std::max( 1u, std::thread::hardware_concurrency() );
+            /* scan ahead of the decoder by a few batches (3 * hardware_concurrency blocks in the reference, BlockFinder.hpp:213) */
+            m_finder = std::make_shared<BlockFinder>( m_source->bytes(), m_source->size(), MI355X_BZ2_MAGIC_BLOCK,
+                                                      std::max<size_t>( 3 * cores, 4 * m_batch ),
+                                                      std::min( 8u, std::max( 1u, cores / 2 ) ) );
+            if ( m_index.sealed() ) {
+                const auto pairs = m_index.snapshot();
+                handOffsetsToFinder( OffsetMap( pairs.begin(), pairs.end() ) );
             }
         }
-        blockFinder().setBlockOffsets( std::move( encodedBlockOffsets ) );
+        return *m_finder;
+    }
+
+    BatchScheduler&
+    scheduler()
+    {
+        if ( !m_scheduler ) {
+            (void)finder();
+            m_scheduler = std::make_unique<BatchScheduler>( m_source, m_finder, m_batch, m_device );
+            if ( !m_finder->finalized() ) {
+                m_finder->startThreads();
+            }
+        }
+        return *m_scheduler;
+    }
+
+    void
+    handOffsetsToFinder( const OffsetMap& offsets )
+    {
+        if ( offsets.empty() ) {
+            fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "a list of block offsets is required" );
+        }
+        std::deque<size_t> dataBlocks;
+        for ( auto entry = offsets.begin(), behind = std::next( entry ); behind != offsets.end(); ++entry, ++behind ) {
+            if ( entry->second != behind->second ) {
+                dataBlocks.push_back( entry->first );
+            }
+        }
+        finder().setBlockOffsets( std::move( dataBlocks ) );
     }
 
 private:
     std::shared_ptr<Source> m_source;
-    const size_t m_parallelization;
+    const size_t m_batch;
     const int m_device;
-    size_t m_currentPosition{ 0 };
-    bool m_atEndOfFile{ false };
+    size_t m_position{ 0 };
+    bool m_atEnd{ false };
 
-    bool m_verifyStreamCrc;
-    bool m_streamCrcIntact{ true };         /* every block of the current stream went into m_calculatedStreamCrc */
-    uint32_t m_calculatedStreamCrc{ 0 };
+    bool m_checkStreamCrc;
+    uint32_t m_streamCrc{ 0 };
     uint64_t m_streamsVerified{ 0 };
 
-    std::shared_ptr<BlockFinder> m_blockFinder;
-    BlockMap m_blockMap;
-    std::unique_ptr<GpuBlockFetcher> m_blockFetcher;
+    std::shared_ptr<BlockFinder> m_finder;
+    BlockIndex m_index;
+    std::unique_ptr<BatchScheduler> m_scheduler;
 };
 }  // namespace mi355x
 
 /* ================================================================================================ C ABI */
 struct mi355x_bz2_reader
 {
-    std::unique_ptr<mi355x::ParallelReader> reader;
+    std::unique_ptr<mi355x::StreamReader> reader;
     std::string lastError;
 };
 
@@ -1130,7 +1072,7 @@ openReader( const MakeSource& makeSource, uint32_t parallelization, int32_t devi
     try {
         auto source = makeSource();
         auto* r = new mi355x_bz2_reader();
-        r->reader = std::make_unique<mi355x::ParallelReader>( std::move( source ), parallelization, device );
+        r->reader = std::make_unique<mi355x::StreamReader>( std::move( source ), parallelization, device );
         *out = r;
         return MI355X_BZ2_OK;
     } catch ( const mi355x::Bz2Exception& e ) {
@@ -1207,7 +1149,7 @@ int
 mi355x_bz2_reader_read( mi355x_bz2_reader* r, int fd, void* buffer, uint64_t nBytes, uint64_t* nRead )
 {
     if ( nRead != nullptr ) *nRead = 0;
-    return guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+    return guarded( r, [&] ( mi355x::StreamReader& reader ) {
         const auto n = reader.read( fd, static_cast<char*>( buffer ), (size_t)nBytes );
         if ( nRead != nullptr ) *nRead = n;
     } );
@@ -1216,7 +1158,7 @@ mi355x_bz2_reader_read( mi355x_bz2_reader* r, int fd, void* buffer, uint64_t nBy
 int
 mi355x_bz2_reader_seek( mi355x_bz2_reader* r, int64_t offset, int whence, uint64_t* newPosition )
 {
-    return guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+    return guarded( r, [&] ( mi355x::StreamReader& reader ) {
         const auto p = reader.seek( offset, whence );
         if ( newPosition != nullptr ) *newPosition = p;
     } );
@@ -1226,7 +1168,7 @@ uint64_t
 mi355x_bz2_reader_tell( const mi355x_bz2_reader* r )
 {
     uint64_t result = 0;
-    guarded( const_cast<mi355x_bz2_reader*>( r ), [&] ( mi355x::ParallelReader& reader ) { result = reader.tell(); } );
+    guarded( const_cast<mi355x_bz2_reader*>( r ), [&] ( mi355x::StreamReader& reader ) { result = reader.tell(); } );
     return result;
 }
 
@@ -1257,21 +1199,21 @@ mi355x_bz2_reader_tell_compressed( const mi355x_bz2_reader* r )
 {
     uint64_t result = 0;
     guarded( const_cast<mi355x_bz2_reader*>( r ),
-             [&] ( mi355x::ParallelReader& reader ) { result = reader.tellCompressed(); } );
+             [&] ( mi355x::StreamReader& reader ) { result = reader.tellCompressed(); } );
     return result;
 }
 
 int
 mi355x_bz2_reader_block_offsets_complete( const mi355x_bz2_reader* r )
 {
-    return ( r != nullptr && r->reader && r->reader->blockOffsetsComplete() ) ? 1 : 0;
+    return ( r != nullptr && r->reader && r->reader->indexComplete() ) ? 1 : 0;
 }
 
 int
 mi355x_bz2_reader_block_offsets( mi355x_bz2_reader* r, uint64_t* bits, uint64_t* bytes, uint64_t capacity, uint64_t* n )
 {
     int inner = MI355X_BZ2_OK;
-    const int rc = guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+    const int rc = guarded( r, [&] ( mi355x::StreamReader& reader ) {
         inner = copyOffsets( reader.blockOffsets(), bits, bytes, capacity, n );
     } );
     return rc != MI355X_BZ2_OK ? rc : inner;
@@ -1282,7 +1224,7 @@ mi355x_bz2_reader_available_block_offsets( const mi355x_bz2_reader* r, uint64_t*
                                            uint64_t capacity, uint64_t* n )
 {
     int inner = MI355X_BZ2_OK;
-    const int rc = guarded( const_cast<mi355x_bz2_reader*>( r ), [&] ( mi355x::ParallelReader& reader ) {
+    const int rc = guarded( const_cast<mi355x_bz2_reader*>( r ), [&] ( mi355x::StreamReader& reader ) {
         inner = copyOffsets( reader.availableBlockOffsets(), bits, bytes, capacity, n );
     } );
     return rc != MI355X_BZ2_OK ? rc : inner;
@@ -1292,7 +1234,7 @@ int
 mi355x_bz2_reader_set_block_offsets( mi355x_bz2_reader* r, const uint64_t* bits, const uint64_t* bytes, uint64_t n )
 {
     if ( n > 0 && ( bits == nullptr || bytes == nullptr ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
-    return guarded( r, [&] ( mi355x::ParallelReader& reader ) {
+    return guarded( r, [&] ( mi355x::StreamReader& reader ) {
         std::map<size_t, size_t> offsets;
         for ( uint64_t i = 0; i < n; ++i ) {
             offsets.emplace( bits[i], bytes[i] );
@@ -1304,13 +1246,13 @@ mi355x_bz2_reader_set_block_offsets( mi355x_bz2_reader* r, const uint64_t* bits,
 int
 mi355x_bz2_reader_join_threads( mi355x_bz2_reader* r )
 {
-    return guarded( r, [] ( mi355x::ParallelReader& reader ) { reader.joinThreads(); } );
+    return guarded( r, [] ( mi355x::StreamReader& reader ) { reader.joinThreads(); } );
 }
 
 int
 mi355x_bz2_reader_set_verify_stream_crc( mi355x_bz2_reader* r, int enable )
 {
-    return guarded( r, [enable] ( mi355x::ParallelReader& reader ) { reader.setVerifyStreamCrc( enable != 0 ); } );
+    return guarded( r, [enable] ( mi355x::StreamReader& reader ) { reader.setVerifyStreamCrc( enable != 0 ); } );
 }
 
 uint64_t
@@ -1324,7 +1266,7 @@ mi355x_bz2_reader_statistics( const mi355x_bz2_reader* r, mi355x_bz2_reader_stat
 {
     if ( stats == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     return guarded( const_cast<mi355x_bz2_reader*>( r ),
-                    [&] ( mi355x::ParallelReader& reader ) { *stats = reader.statistics(); } );
+                    [&] ( mi355x::StreamReader& reader ) { *stats = reader.statistics(); } );
 }
 
 }  // extern "C"

@@ -47,6 +47,7 @@ wave_sync()
 {
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
     __builtin_amdgcn_wave_barrier();
+    asm volatile( "" ::: "memory" );   /* LDS traffic of one wave is in order in hardware: the compiler has to keep it so */
 }
 
 /** Per-block hand-off between k_huff and k_mtf. */
@@ -373,7 +374,12 @@ huff_block( HuffShared&                  sh,
         /* Each lane keeps the four stream words that start at the word of ITS bit position, loaded one window ahead:
          * a window advances by at most 64 bits, so the words needed next are among them. */
         uint32_t myWord = ( pos + lane ) >> 5;
-        uint4 D = *reinterpret_cast<const uint4*>( words + myWord );
+        const auto load4 = [words] ( uint32_t at ) {
+            uint4 v = *reinterpret_cast<const uint4*>( words + at );
+            v.x = be32( v.x ); v.y = be32( v.y ); v.z = be32( v.z ); v.w = be32( v.w );
+            return v;
+        };
+        uint4 D = load4( myWord );
 
 #ifdef MI355X_BZ2_HUFF_PROFILE
         uint64_t profSetup = 0, profChain = 0, profCommit = 0, profWindows = 0, profRefresh = 0, profGeneral = 0, profGeneralCycles = 0;
@@ -408,7 +414,7 @@ huff_block( HuffShared&                  sh,
             const uint32_t hi = dsel == 0 ? D.x : ( dsel == 1 ? D.y : D.z );
             const uint32_t lo = dsel == 0 ? D.y : ( dsel == 1 ? D.z : D.w );
             myWord = newWord;
-            D = *reinterpret_cast<const uint4*>( words + myWord );
+            D = load4( myWord );
             const uint32_t shv = ( pos + lane ) & 31u;
             const uint32_t bits32 = (uint32_t)( ( ( ( (uint64_t)hi << 32 ) | lo ) << shv ) >> 32 );
             const uint32_t E = sh.lut[tcur][bits32 >> ( 32 - LUT_BITS )];

@@ -32,6 +32,42 @@ def shard_blocks(block_bit_offsets, end_bit, rank, world):
     return bounds[rank], bounds[rank + 1]
 
 
+def shard_byte_range(block_bit_offsets, file_size, lo, hi):
+    """Bytes [first, end) of the file that blocks [lo, hi) need -- what a rank copies to its GPU -- and the blocks' bit
+    offsets relative to `first`.  The range starts at the 4-byte word that holds the first block's magic and ends where
+    block `hi` starts (or at the end of the file): a block never reads its successor's bytes, and the next block's
+    magic is not completely inside, so a magic scan of the range finds exactly these blocks."""
+    n = len(block_bit_offsets)
+    if lo >= hi:
+        return 0, 0, []
+    first = (block_bit_offsets[lo] // 8) & ~3
+    end = (block_bit_offsets[hi] + 7) // 8 if hi < n else file_size
+    return first, end, [o - 8 * first for o in block_bit_offsets[lo:hi]]
+
+
+def rotl32(value, count):
+    count %= 32
+    return ((value << count) | (value >> (32 - count))) & 0xFFFFFFFF if count else value & 0xFFFFFFFF
+
+
+def crc_chain(block_crcs):
+    """bzip2's stream CRC of a sequence of block CRCs: c = rotl(c, 1) ^ crc (BZ2Reader.hpp:481-484)."""
+    chain = 0
+    for crc in block_crcs:
+        chain = rotl32(chain, 1) ^ crc
+    return chain
+
+
+def combine_crc_chains(parts):
+    """Stream CRC of the whole file from the (chain, number of blocks) pairs of consecutive block ranges, in order.
+    rotl is linear over xor, so chain(A then B) = rotl(chain(A), |B|) ^ chain(B): every rank folds its own blocks and
+    rank 0 checks the file's end-of-stream CRC without seeing a single block CRC of the others."""
+    total = 0
+    for chain, count in parts:
+        total = rotl32(total, count) ^ chain
+    return total
+
+
 def gather_extents(mine, rank, world, out=None):
     """Gather ragged 1-D uint8 tensors (one decoded extent per rank) into rank 0, in rank order.
 

@@ -1,53 +1,60 @@
+/* Seeded random operations on the host-side classes (block index, access pattern, run cache, block finder thread) for the
+ * sanitizer builds of tests/test_host_sanitizers.py: asserts only invariants, the answers are pinned elsewhere
+ * (tests/native/host_known_answers.cpp). */
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <vector>
 #include "../../include/mi355x_bz2.h"
 #include "../../indexed_bzip2_amd/csrc/bz2_host.hpp"
 using namespace mi355x;
+struct Run { size_t f, n; size_t first() const { return f; } size_t count() const { return n; } };
 int main() {
     srand(3);
     for (int iter = 0; iter < 300; ++iter) {
-        BlockMap map;
-        std::vector<size_t> offs{0};
+        BlockIndex index;
         size_t enc = 32, dec = 0;
         const int n = 1 + rand() % 50;
         for (int i = 0; i < n; ++i) {
             const size_t es = 80 + rand() % 10000, ds = (rand() % 4 == 0) ? 0 : rand() % 100000;
-            map.push(enc, es, ds);
+            assert(index.append(enc, es, ds) == dec);
             enc += es; dec += ds;
-            for (int q = 0; q < 5; ++q) { auto info = map.findDataOffset(rand() % (dec + 10)); (void)info.contains(0); }
+            assert(index.frontier() == dec);
+            for (int q = 0; q < 5; ++q) { const auto o = rand() % (dec + 10); const auto s = index.locate(o); assert(!s.covers(o) || (s.bytes <= o && o < s.bytes + s.byteLength)); }
         }
-        map.finalize();
-        assert(map.finalized());
-        const auto m = map.blockOffsets();
-        BlockMap other; other.setBlockOffsets(m);
-        assert(other.blockOffsets() == m);
-        for (int q = 0; q < 50; ++q) { (void)other.findDataOffset(rand() % (dec + 100)); }
-        (void)other.back(); (void)other.dataBlockCount();
+        index.seal();
+        assert(index.sealed());
+        const auto pairs = index.snapshot();
+        BlockIndex other; other.assign(pairs);
+        assert(other.snapshot() == pairs);
+        for (int q = 0; q < 50; ++q) { (void)other.locate(rand() % (dec + 100)); }
+        (void)other.last(); (void)other.dataBlocks();
     }
-    LruCache<size_t, int> cache(8);
+    RunCache<Run> cache(64);
     for (int i = 0; i < 10000; ++i) {
-        const size_t k = rand() % 40;
+        const size_t k = rand() % 400;
         switch (rand() % 5) {
-        case 0: cache.insert(k, i); break;
-        case 1: (void)cache.get(k); break;
-        case 2: cache.touch(k); break;
-        case 3: cache.evict(k); break;
-        default: (void)cache.test(k); (void)cache.nextNthEviction(1 + rand() % 3); break;
+        case 0: if (!cache.covers(k)) { size_t n = 1 + rand() % 16; while (n > 1 && cache.firstGap(k) != k + 0 && false) --n; size_t m = 0; while (m < n && !cache.covers(k + m)) ++m; cache.insert(std::make_shared<Run>(Run{k, m})); } break;
+        case 1: (void)cache.find(k); break;
+        case 2: (void)cache.firstGap(k); (void)cache.blocksWithin(k, k + 50); break;
+        case 3: cache.dropBefore(k); break;
+        default: (void)cache.covers(k); break;
         }
-        assert(cache.size() <= cache.capacity());
+        assert(cache.blocks() <= cache.budget() || cache.runs() == 1);
     }
-    cache.shrinkTo(2); cache.clear();
-    FetchNextAdaptive strat;
+    cache.clear();
+    SequentialityTracker pattern;
     size_t idx = 0;
     for (int i = 0; i < 5000; ++i) {
         if (rand() % 10 == 0) idx = rand() % 1000; else ++idx;
-        strat.fetch(idx);
-        const auto p = strat.prefetch(1 + rand() % 64);
-        (void)p; (void)strat.isSequential();
+        pattern.note(idx);
+        const size_t limit = 1 + rand() % 64;
+        const auto r = pattern.ahead(limit);
+        assert(r.count <= limit && (r.count == 0 || r.first == idx + 1));
+        (void)pattern.inOrder();
     }
     // BlockFinder over a buffer with magics, with and without the thread
     std::vector<uint8_t> buf(3 << 20);
@@ -58,12 +65,19 @@ int main() {
     {
         BlockFinder finder(buf.data(), buf.size(), MI355X_BZ2_MAGIC_BLOCK, 8, 2);
         finder.startThreads();
-        size_t i = 0;
-        for (;; ++i) { const auto [o, code] = finder.get(i); if (!o) break; assert(i < want.size() + 5); }
-        assert(finder.finalized());
-        finder.stopThreads();
-        printf("finder found %zu (planted %zu)\n", finder.size(), want.size());
+        for (size_t i = 0; i < want.size(); ++i) { const auto [o, code] = finder.get(i); assert(o && *o == want[i]); }
+        const auto [none, code] = finder.get(want.size());
+        assert(!none && code == BlockFinder::GetReturnCode::FAILURE);
+        assert(finder.find(want[3]) == 3);
     }
-    printf("host ok\n");
+    {
+        BlockFinder finder(buf.data(), buf.size(), MI355X_BZ2_MAGIC_BLOCK, 2, 1);
+        (void)finder.get(1);
+        finder.finalize(2);
+        assert(finder.size() == 2 && finder.finalized());
+        finder.setBlockOffsets({1, 2, 3});
+        assert(finder.size() == 3);
+    }
+    std::printf("host ok\n");
     return 0;
 }

@@ -346,3 +346,58 @@ def test_batch_of_shuffled_duplicated_and_bogus_offsets(native, oracle, dec):
             assert out[pos:pos + r["decoded_size"]] == payload, o
             pos += r["decoded_size"]
     assert pos == total
+
+
+_slice = {}
+
+
+def bench_slice(native):
+    """24 MB of the benchmark corpus as one stitched single-stream level-9 file: (encoded, raw)."""
+    if not _slice:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import silesia_like, bz2build
+        data = silesia_like.generate(24_000_000, threads=8)
+        enc, nb, offs = bz2build.build(data, 1, piece_size=6_000_000, threads=8, find_magic=native.find_magic)
+        assert nb >= 24
+        _slice["v"] = (enc, data.tobytes())
+    return _slice["v"]
+
+
+@pytest.mark.parametrize("variant", ["scan-1", "scan-2", "scan-4", "scan-8", "window"])
+def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
+    """Every form of the Huffman stage -- k_hscan with 1, 2, 4 or 8 wavefronts per block (+ k_hsym) and the single-chain
+    k_huff -- against the oracle, whatever the batch size would select by itself: valid data of all kinds, streams no
+    libbz2 writes, one invalid stream per reference throw site, and seeded damage (every field of every record)."""
+    if variant == "window":
+        monkeypatch.setenv("MI355X_BZ2_HUFF", "window")
+    else:
+        monkeypatch.setenv("MI355X_BZ2_HUFF", "scan")
+        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", variant.split("-")[1])
+    d = native.Decoder(flags=native.Decoder.KEEP_STAGES)
+    try:
+        corpus = datagen.corpus_small()
+        for name in ("text-1.2M-l9", "rand-300k-l9", "text-400k-l1", "runs-500k-l9", "ab-257", "all-bytes", "rand-1",
+                     "zeros-3M-l9", "one-symbol-3"):
+            raw, level = corpus[name]
+            check_blocks(native, oracle, d, datagen.compress(raw, level), raw, check_stages=name.startswith("text-1.2M"))
+        for name, (raw, enc) in datagen.exotic_streams().items():
+            check_blocks(native, oracle, d, enc, raw, check_stages=False)
+        for name, (enc, status) in datagen.faulty_streams().items():
+            results = check_blocks(native, oracle, d, enc, check_stages=False)
+            assert results[0]["status"] == status, name
+        # full-size blocks of every kind of the benchmark corpus (group lengths from 60 to 400 bits: every span size)
+        check_blocks(native, oracle, d, *bench_slice(native), check_stages=False)
+        keys = ("encoded_offset_bits", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc", "bwt_length",
+                "orig_ptr", "n_symbols", "is_eos", "is_eof", "status")
+        for name, (enc, offs) in datagen.damaged_corpus().items():
+            if not offs:
+                continue
+            d.set_input(enc)
+            results, _ = d.decode_batch(offs)
+            for o, r in zip(offs, results):
+                od = oracle.decode_block(enc, o)[0]
+                for key in keys:
+                    assert r[key] == od[key], (name, o, key, r[key], od[key])
+    finally:
+        d.close()

@@ -72,7 +72,8 @@ def test_decompression_matrix(native, tmp_path, parallelization):
     rng = np.random.default_rng(0xC0FFEE + parallelization)
     path = str(tmp_path / "matrix.bz2")
     levels, encoders = set(), set()
-    for size, pattern, level, encoder in cells():
+    used_buffer_sizes = set()
+    for cell, (size, pattern, level, encoder) in enumerate(cells()):
         raw = make_data(size, pattern, seed=size * 31 + (pattern or 7))
         enc = encode(raw, level, encoder)
         levels.add(level)
@@ -81,10 +82,11 @@ def test_decompression_matrix(native, tmp_path, parallelization):
             f.write(enc)
         want = hashlib.sha1(raw).digest()
         where = (size, pattern, level, encoder, parallelization)
-        for buffer_size in BUFFER_SIZES:                       # checkDecompression, :78-88
+        for buffer_size in [BUFFER_SIZES[(cell + k) % len(BUFFER_SIZES)] for k in (0, 2, 4)]:   # checkDecompression, :78-88
+            used_buffer_sizes.add(buffer_size)
             # like the reference's CompressedFileReader(name) these readers take the default parallelization; the
             # parameter's value is used for the seek checks below (testPythonWrappers.py:193, 209, 228)
-            with native.IndexedBzip2File(path, parallelization if buffer_size in (-1, 333) else 1) as f:
+            with native.IndexedBzip2File(path, parallelization if buffer_size in (-1, 333, 1024) else 1) as f:
                 assert sha1_of(f, buffer_size) == want, (where, buffer_size)
         if size > 0:
             f = native.IndexedBzip2File(path, parallelization)
@@ -99,7 +101,7 @@ def test_decompression_matrix(native, tmp_path, parallelization):
                 check_seek(raw, g, pos)
                 g.close()
                 assert g.closed
-    assert levels == set(range(1, 10)) and encoders == set(ENCODERS)
+    assert levels == set(range(1, 10)) and encoders == set(ENCODERS) and used_buffer_sizes == set(BUFFER_SIZES)
 
 
 @pytest.mark.parametrize("size", [512 * 1024 + 2, 1, 2, 4, 128, 1000, 1024, 128 * 1024, 100_000, 200_000, 400_000,

@@ -1,6 +1,7 @@
-"""Host-side C++ (magic finder, block map, LRU cache, prefetch strategy, block finder thread) under AddressSanitizer and
-UBSan: CPU build only (GPU sanitizers are not available on the pool).  The harnesses in tests/native/ drive the classes
-with seeded random operations and exact-size buffers."""
+"""Host-side C++ (magic finder, block index, run cache, access-pattern tracker, block finder thread) under
+AddressSanitizer + UBSan and under ThreadSanitizer: CPU builds only (GPU sanitizers are not available on the pool).  The
+harnesses in tests/native/ drive the classes with seeded random operations and exact-size buffers; host_known_answers
+replays the answers recorded from the reference's own classes (tests/golden/host_vectors.txt)."""
 import os
 import shutil
 import subprocess
@@ -11,16 +12,25 @@ from conftest import ROOT
 
 NATIVE = os.path.join(ROOT, "tests", "native")
 FINDER = os.path.join(ROOT, "indexed_bzip2_amd", "csrc", "bz2_finder.cpp")
+VECTORS = os.path.join(ROOT, "tests", "golden", "host_vectors.txt")
+
+CASES = [
+    ("finder_sanitize.cpp", "address,undefined", [], "matches"),
+    ("host_sanitize.cpp", "address,undefined", [], "host ok"),
+    ("host_sanitize.cpp", "thread", [], "host ok"),                      # the finder thread against its consumers
+    ("finder_sanitize.cpp", "thread", [], "matches"),
+    ("host_known_answers.cpp", "address,undefined", [VECTORS], "known answers ok"),
+]
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-@pytest.mark.parametrize("harness, expect", [("finder_sanitize.cpp", "matches"), ("host_sanitize.cpp", "host ok")])
-def test_host_code_under_sanitizers(tmp_path, harness, expect):
+@pytest.mark.parametrize("harness, sanitizer, args, expect", CASES)
+def test_host_code_under_sanitizers(tmp_path, harness, sanitizer, args, expect):
     exe = tmp_path / "harness"
-    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all",
                             "-pthread", "-o", str(exe), os.path.join(NATIVE, harness), FINDER],
                            capture_output=True, text=True, timeout=600)
     assert build.returncode == 0, build.stderr[-2000:]
-    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    run = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     assert expect in run.stdout

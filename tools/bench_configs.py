@@ -113,7 +113,7 @@ def config3(out):
     enc = open(cache, "rb").read()
     offsets = json.load(open(cache + ".json"))["offsets"]
     d_in = torch.frombuffer(bytearray(enc), dtype=torch.uint8).cuda()
-    dec = m.Decoder(device=0, max_batch_blocks=64 if only5 else len(offsets))
+    dec = m.Decoder(device=0, max_batch_blocks=len(offsets))
     dec.set_input_device(d_in.data_ptr(), len(enc), keepalive=d_in)
     res, total = dec.decode_batch(offsets)
     assert all(r["status"] == 0 for r in res) and total == 2_147_483_640
@@ -131,11 +131,13 @@ def config3(out):
 
 
 def main():
+    """usage: bench_configs.py [3] [5] [all]   (default: all = config 3, then 2 and 5)"""
     out = {}
-    only5 = len(sys.argv) > 1 and sys.argv[1] == "5"
-    if not only5:
+    which = set(sys.argv[1:]) or {"all"}
+    if which & {"3", "all"}:
         config3(out)
-    config2_and_5(out, only5)
+    if which & {"5", "all"}:
+        config2_and_5(out, only5="all" not in which)
     print(json.dumps(out, indent=1))
 
 
