@@ -137,15 +137,16 @@ def main():
     ap.add_argument("--contexts", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="decoder contexts used in turn: step k+1 is queued on the next context before step k is "
                          "finished, so its transfer and its latency-bound first kernels overlap the kernels of step k.  "
-                         "0 = 2 for one GPU (2 560 blocks per step keep the GPU busy) and 4 for N > 1, where a rank's "
-                         "share of the file is small and a step's duration is the latency of its largest block")
+                         "0 = 3 for one GPU (2 560 blocks per step keep the GPU busy; the third context hides the H2D "
+                         "copy: 82 instead of 87 ms per step) and 4 for N > 1, where a rank's share of the file is small "
+                         "and a step's duration is the latency of its largest block")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on ONE GPU: ranks share cuda:0 and extents travel via host memory")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.contexts == 0:
-        args.contexts = 2 if world_env == 1 else 4
+        args.contexts = 3 if world_env == 1 else 4
     # every decoder context drives up to 4 HIP streams: without this the runtime maps them onto 4 hardware queues and
     # streams that share a queue serialize (must be set before the HIP runtime starts)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.contexts))
@@ -337,11 +338,11 @@ def main():
         launch_ms = dt / steps * 1e3
         achieved = alg_bytes / (launch_ms / 1e3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("workload_blocks") == n_blocks:
-                traffic = tj.get("hbm_bytes_per_step")
+        # PMC traffic of one step of this workload (tools/profile_round.sh traffic: separate FETCH_SIZE / WRITE_SIZE passes,
+        # corrected as calibrated by tools/fetch_calib.sh), measured for the single-GPU case
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic_bench.json")
+        if os.path.exists(tpath) and world == 1 and n_blocks == 2560:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         out = {
             "metric": "decompressed MB/s (whole node), 2 GiB Silesia bz2-9",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,

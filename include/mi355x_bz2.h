@@ -133,6 +133,14 @@ const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
  * Replaces the BitReader/SharedFileReader clone + pread of BZ2BlockFetcher.hpp:89-90. */
 int mi355x_bz2_set_input_host( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
 int mi355x_bz2_set_input_host_async( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
+/* _host_streamed returns at once and copies in the background, in 32-MiB pieces on a thread and a stream of its own
+ * (pageable memory is fine: a memory-mapped file): every decode_batch[_begin] waits only for the pieces in which its
+ * blocks lie, so the first blocks of a large file decode while the rest is still on its way
+ * (mi355x_bz2_find_magic_device needs all of it and waits for all of it).  `bytes` must stay valid until
+ * mi355x_bz2_input_resident returns 1, the next set_input_* or the destruction of the context.  Contexts that share the
+ * input (mi355x_bz2_share_input) share the copy in progress. */
+int mi355x_bz2_set_input_host_streamed( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
+int mi355x_bz2_input_resident( const mi355x_bz2_ctx* ctx );
 int mi355x_bz2_set_input_device( mi355x_bz2_ctx* ctx, const void* device_bytes, uint64_t size );
 /* Several contexts over ONE resident copy of the input (the reader keeps two contexts to overlap consecutive batches):
  * `ctx` decodes from the bytes `from` made resident.  Nothing is copied; `from` must outlive `ctx`'s use of them and

@@ -92,6 +92,8 @@ SYMBOLS = [
     ("mi355x_bz2_last_error", ctypes.c_char_p, [_vp]),
     ("mi355x_bz2_set_input_host", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64]),
     ("mi355x_bz2_set_input_host_async", ctypes.c_int, [_vp, ctypes.c_void_p, ctypes.c_uint64]),
+    ("mi355x_bz2_set_input_host_streamed", ctypes.c_int, [_vp, ctypes.c_void_p, ctypes.c_uint64]),
+    ("mi355x_bz2_input_resident", ctypes.c_int, [_vp]),
     ("mi355x_bz2_set_input_device", ctypes.c_int, [_vp, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_decode_batch", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.POINTER(BlockResult), _u64p]),
     ("mi355x_bz2_decode_batch_begin", ctypes.c_int, [_vp, _u64p, ctypes.c_uint32]),

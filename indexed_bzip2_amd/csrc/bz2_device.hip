@@ -13,8 +13,11 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mi355x_bz2.h"
@@ -28,6 +31,48 @@ using namespace bz2gpu;
 constexpr uint32_t MAX_CHUNKS = 3;          /* groups of cheap blocks; one more stream than hardware queues (4 by
                                                default) would serialize two groups */
 constexpr int MAX_GROUPS = MAX_CHUNKS + 1;   /* + the expensive group */
+
+/** A host -> HBM copy of the input that runs in pieces on a thread and a stream of its own
+ * (mi355x_bz2_set_input_host_streamed): a batch only waits for the piece in which its last block ends.  Shared by the
+ * contexts that share the input. */
+struct InputUpload
+{
+    static constexpr uint64_t PIECE = uint64_t( 32 ) << 20;
+    static constexpr uint64_t HEAD = uint64_t( 64 ) << 20;   /* files beyond this get their beginning a second time, see below */
+
+    /* Allocating the copy of a multi-GB file takes longer (page clearing, up to 70 ms per GB) than decoding its first
+     * blocks: the first HEAD bytes go into a small buffer of their own first, from which batches that lie wholly inside
+     * decode while the full buffer is still being allocated and filled by the thread. */
+    uint8_t* head{ nullptr };
+    uint64_t headBytes{ 0 };
+    bool headQueued{ false };
+    hipEvent_t headDone{ nullptr };
+    uint8_t* main{ nullptr };      /* the whole file; allocated by the thread */
+
+    std::thread worker;
+    std::mutex mutex;
+    std::condition_variable changed;
+    uint64_t queued{ 0 };          /* bytes whose copy is queued on `stream`, with done[piece] recorded behind it */
+    uint64_t total{ 0 };
+    bool failed{ false };
+    int device{ 0 };
+    hipStream_t stream{ nullptr };
+    std::vector<hipEvent_t> done;
+
+    ~InputUpload()
+    {
+        if ( worker.joinable() ) worker.join();
+        (void)hipSetDevice( device );
+        if ( stream ) (void)hipStreamSynchronize( stream );
+        for ( auto& e : done ) {
+            if ( e ) (void)hipEventDestroy( e );
+        }
+        if ( headDone ) (void)hipEventDestroy( headDone );
+        if ( stream ) (void)hipStreamDestroy( stream );
+        (void)hipFree( head );
+        (void)hipFree( main );
+    }
+};
 
 struct mi355x_bz2_ctx
 {
@@ -43,9 +88,12 @@ struct mi355x_bz2_ctx
     uint64_t dInOwnedCapacity{ 0 };
     const uint8_t* dIn{ nullptr };
     uint64_t inSize{ 0 };
+    std::shared_ptr<InputUpload> upload;   /* set while / after a streamed copy of the input */
 
-    /* per-block scratch, capacity in blocks */
+    /* per-block scratch, capacity in blocks: one device and one page-locked host allocation, carved up by ensureScratch */
     uint32_t capacity{ 0 };
+    uint8_t* dScratch{ nullptr };
+    uint8_t* hScratch{ nullptr };
     uint64_t* dOffsets{ nullptr };
     uint32_t* dOrder{ nullptr };
     uint32_t* hOrder{ nullptr };       /* pinned */
@@ -144,35 +192,18 @@ initCrcConsts( CrcConsts& cc )
 void
 freeScratch( mi355x_bz2_ctx* c )
 {
-    (void)hipFree( c->dOffsets ); c->dOffsets = nullptr;
-    (void)hipFree( c->dOrder ); c->dOrder = nullptr;
-    (void)hipHostFree( c->hOrder ); c->hOrder = nullptr;
-    (void)hipHostFree( c->hSlotOf ); c->hSlotOf = nullptr;
-    (void)hipFree( c->dMeta ); c->dMeta = nullptr;
-    (void)hipFree( c->dSel ); c->dSel = nullptr;
-    (void)hipFree( c->dSym ); c->dSym = nullptr;
-    (void)hipFree( c->dStb ); c->dStb = nullptr;
-    (void)hipFree( c->dHmeta ); c->dHmeta = nullptr;
-    (void)hipFree( c->dSmeta ); c->dSmeta = nullptr;
-    (void)hipFree( c->dHtab ); c->dHtab = nullptr;
-    (void)hipFree( c->dGpos ); c->dGpos = nullptr;
-    (void)hipFree( c->dL ); c->dL = nullptr;
-    (void)hipFree( c->dTab ); c->dTab = nullptr;
-    (void)hipFree( c->dR ); c->dR = nullptr;
-    (void)hipFree( c->dSegLen ); c->dSegLen = nullptr;
-    (void)hipFree( c->dSegSucc ); c->dSegSucc = nullptr;
-    (void)hipFree( c->dSegOff ); c->dSegOff = nullptr;
-    (void)hipFree( c->dSegCont ); c->dSegCont = nullptr;
-    (void)hipFree( c->dChain ); c->dChain = nullptr;
-    (void)hipFree( c->dStash ); c->dStash = nullptr;
-    (void)hipFree( c->dPlan ); c->dPlan = nullptr;
-    (void)hipFree( c->dWalkBlk ); c->dWalkBlk = nullptr;
-    (void)hipFree( c->dWalkPre ); c->dWalkPre = nullptr;
-    (void)hipHostFree( c->hMeta ); c->hMeta = nullptr;
-    (void)hipHostFree( c->hOffsets ); c->hOffsets = nullptr;
+    (void)hipFree( c->dScratch ); c->dScratch = nullptr;
+    (void)hipHostFree( c->hScratch ); c->hScratch = nullptr;
+    c->dOffsets = nullptr; c->dOrder = nullptr; c->dMeta = nullptr; c->dSel = nullptr; c->dSym = nullptr; c->dStb = nullptr;
+    c->dHmeta = nullptr; c->dSmeta = nullptr; c->dHtab = nullptr; c->dGpos = nullptr; c->dL = nullptr; c->dTab = nullptr;
+    c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegOff = nullptr; c->dSegCont = nullptr;
+    c->dChain = nullptr; c->dStash = nullptr; c->dPlan = nullptr; c->dWalkBlk = nullptr; c->dWalkPre = nullptr;
+    c->hOrder = nullptr; c->hSlotOf = nullptr; c->hMeta = nullptr; c->hOffsets = nullptr;
     c->capacity = 0;
 }
 
+/** Per-block scratch for `nBlocks` blocks: ONE device allocation and ONE page-locked host allocation, carved into the
+ * buffers (two dozen separate allocations cost 80 ms per context, which a reader pays before its first byte). */
 int
 ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
 {
@@ -183,32 +214,70 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     uint32_t cap = 8;
     while ( cap < nBlocks && cap < 512 ) cap *= 2;
     if ( cap < nBlocks ) cap = ( nBlocks + 255u ) & ~255u;
-    HIP_TRY( c, hipMalloc( &c->dOffsets, (size_t)cap * sizeof( uint64_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dOrder, (size_t)cap * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipHostMalloc( &c->hOrder, (size_t)cap * sizeof( uint32_t ), hipHostMallocDefault ) );
-    HIP_TRY( c, hipMalloc( &c->dMeta, (size_t)cap * sizeof( BlockMeta ) ) );
-    HIP_TRY( c, hipMalloc( &c->dSel, (size_t)cap * SEL_STRIDE + 256 ) );
-    HIP_TRY( c, hipMalloc( &c->dSym, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dStb, (size_t)cap * 256 ) );
-    HIP_TRY( c, hipMalloc( &c->dHmeta, (size_t)cap * sizeof( HuffMeta ) ) );
-    HIP_TRY( c, hipMalloc( &c->dSmeta, (size_t)cap * sizeof( ScanMeta ) ) );
-    HIP_TRY( c, hipMalloc( &c->dHtab, (size_t)cap * sizeof( HuffTables ) ) );
-    HIP_TRY( c, hipMalloc( &c->dGpos, (size_t)cap * GPOS_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dL, (size_t)cap * L_STRIDE + 256 ) );
-    HIP_TRY( c, hipMalloc( &c->dTab, (size_t)cap * TAB_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dR, (size_t)cap * L_STRIDE + 256 ) );
-    HIP_TRY( c, hipMalloc( &c->dSegLen, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dSegSucc, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dSegOff, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dSegCont, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dChain, (size_t)cap * SEG_STRIDE * sizeof( uint4 ) ) );
-    HIP_TRY( c, hipMalloc( &c->dStash, (size_t)cap * SEG_STRIDE * STASH_BYTES ) );
-    HIP_TRY( c, hipMalloc( &c->dPlan, MAX_GROUPS * sizeof( WalkPlan ) ) );
-    HIP_TRY( c, hipMalloc( &c->dWalkBlk, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipMalloc( &c->dWalkPre, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) ) );
-    HIP_TRY( c, hipHostMalloc( &c->hSlotOf, (size_t)cap * sizeof( uint32_t ), hipHostMallocDefault ) );
-    HIP_TRY( c, hipHostMalloc( &c->hMeta, (size_t)cap * sizeof( BlockMeta ), hipHostMallocDefault ) );
-    HIP_TRY( c, hipHostMalloc( &c->hOffsets, (size_t)cap * sizeof( uint64_t ), hipHostMallocDefault ) );
+
+    size_t deviceBytes = 0, hostBytes = 0;
+    const auto reserve = [] ( size_t& total, size_t bytes ) {
+        const size_t at = total;
+        total += ( bytes + 255 ) & ~size_t( 255 );
+        return at;
+    };
+    const size_t oOffsets = reserve( deviceBytes, (size_t)cap * sizeof( uint64_t ) );
+    const size_t oOrder = reserve( deviceBytes, (size_t)cap * sizeof( uint32_t ) );
+    const size_t oMeta = reserve( deviceBytes, (size_t)cap * sizeof( BlockMeta ) );
+    const size_t oSel = reserve( deviceBytes, (size_t)cap * SEL_STRIDE + 256 );
+    const size_t oSym = reserve( deviceBytes, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) );
+    const size_t oStb = reserve( deviceBytes, (size_t)cap * 256 );
+    const size_t oHmeta = reserve( deviceBytes, (size_t)cap * sizeof( HuffMeta ) );
+    const size_t oSmeta = reserve( deviceBytes, (size_t)cap * sizeof( ScanMeta ) );
+    const size_t oHtab = reserve( deviceBytes, (size_t)cap * sizeof( HuffTables ) );
+    const size_t oGpos = reserve( deviceBytes, (size_t)cap * GPOS_STRIDE * sizeof( uint32_t ) );
+    const size_t oL = reserve( deviceBytes, (size_t)cap * L_STRIDE + 256 );
+    const size_t oTab = reserve( deviceBytes, (size_t)cap * TAB_STRIDE * sizeof( uint32_t ) );
+    const size_t oR = reserve( deviceBytes, (size_t)cap * L_STRIDE + 256 );
+    const size_t oSegLen = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
+    const size_t oSegSucc = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
+    const size_t oSegOff = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
+    const size_t oSegCont = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
+    const size_t oChain = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint4 ) );
+    const size_t oStash = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * STASH_BYTES );
+    const size_t oPlan = reserve( deviceBytes, MAX_GROUPS * sizeof( WalkPlan ) );
+    const size_t oWalkBlk = reserve( deviceBytes, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) );
+    const size_t oWalkPre = reserve( deviceBytes, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) );
+    const size_t hOrderAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
+    const size_t hSlotOfAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
+    const size_t hMetaAt = reserve( hostBytes, (size_t)cap * sizeof( BlockMeta ) );
+    const size_t hOffsetsAt = reserve( hostBytes, (size_t)cap * sizeof( uint64_t ) );
+
+    HIP_TRY( c, hipMalloc( &c->dScratch, deviceBytes ) );
+    HIP_TRY( c, hipHostMalloc( &c->hScratch, hostBytes, hipHostMallocDefault ) );
+    uint8_t* const d = c->dScratch;
+    uint8_t* const h = c->hScratch;
+    c->dOffsets = reinterpret_cast<uint64_t*>( d + oOffsets );
+    c->dOrder = reinterpret_cast<uint32_t*>( d + oOrder );
+    c->dMeta = reinterpret_cast<BlockMeta*>( d + oMeta );
+    c->dSel = d + oSel;
+    c->dSym = reinterpret_cast<uint16_t*>( d + oSym );
+    c->dStb = d + oStb;
+    c->dHmeta = reinterpret_cast<HuffMeta*>( d + oHmeta );
+    c->dSmeta = reinterpret_cast<ScanMeta*>( d + oSmeta );
+    c->dHtab = reinterpret_cast<HuffTables*>( d + oHtab );
+    c->dGpos = reinterpret_cast<uint32_t*>( d + oGpos );
+    c->dL = d + oL;
+    c->dTab = reinterpret_cast<uint32_t*>( d + oTab );
+    c->dR = d + oR;
+    c->dSegLen = reinterpret_cast<uint32_t*>( d + oSegLen );
+    c->dSegSucc = reinterpret_cast<uint32_t*>( d + oSegSucc );
+    c->dSegOff = reinterpret_cast<uint32_t*>( d + oSegOff );
+    c->dSegCont = reinterpret_cast<uint32_t*>( d + oSegCont );
+    c->dChain = reinterpret_cast<uint4*>( d + oChain );
+    c->dStash = reinterpret_cast<uint32_t*>( d + oStash );
+    c->dPlan = reinterpret_cast<WalkPlan*>( d + oPlan );
+    c->dWalkBlk = reinterpret_cast<uint32_t*>( d + oWalkBlk );
+    c->dWalkPre = reinterpret_cast<uint32_t*>( d + oWalkPre );
+    c->hOrder = reinterpret_cast<uint32_t*>( h + hOrderAt );
+    c->hSlotOf = reinterpret_cast<uint32_t*>( h + hSlotOfAt );
+    c->hMeta = reinterpret_cast<BlockMeta*>( h + hMetaAt );
+    c->hOffsets = reinterpret_cast<uint64_t*>( h + hOffsetsAt );
     c->capacity = cap;
     return MI355X_BZ2_OK;
 }
@@ -377,6 +446,7 @@ mi355x_bz2_destroy( mi355x_bz2_ctx* c )
         if ( c->gstream[g] ) (void)hipStreamSynchronize( c->gstream[g] );
     }
     freeScratch( c );
+    c->upload.reset();   /* joins the copy thread (of the owner; sharers only drop their reference) before the memory goes */
     (void)hipFree( c->dInOwned );
     (void)hipFree( c->dOut );
     for ( auto& group : c->ev ) {
@@ -405,13 +475,10 @@ mi355x_bz2_last_error( const mi355x_bz2_ctx* c )
 
 namespace
 {
-/** Reserve the ctx-owned input copy and queue `size` bytes into it (host or device source) on the ctx stream, zero padded;
- * no wait.  Copies of more than 64 MiB from the host go in pieces, so that the first kernels of another context's batch
- * are not queued behind one long transfer. */
+/** Room for `size` input bytes + padding in the ctx-owned copy. */
 int
-queueInput( mi355x_bz2_ctx* c, const void* bytes, uint64_t size, hipMemcpyKind kind )
+reserveInput( mi355x_bz2_ctx* c, uint64_t size )
 {
-    HIP_TRY( c, hipSetDevice( c->device ) );
     const uint64_t padded = ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256;
     if ( padded > c->dInOwnedCapacity ) {
         HIP_TRY( c, hipStreamSynchronize( c->stream ) );
@@ -421,7 +488,57 @@ queueInput( mi355x_bz2_ctx* c, const void* bytes, uint64_t size, hipMemcpyKind k
         HIP_TRY( c, hipMalloc( &c->dInOwned, padded ) );
         c->dInOwnedCapacity = padded;
     }
-    HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0, padded - ( size & ~uint64_t( 255 ) ), c->stream ) );
+    return MI355X_BZ2_OK;
+}
+
+/** Orders the ctx stream behind the streamed copy of input bytes [0, needed) and says where they are (the head buffer or
+ * the full copy, see InputUpload); waits on the host until that copy is queued.  Without a streamed copy: the resident
+ * input as it is. */
+int
+awaitInput( mi355x_bz2_ctx* c, uint64_t needed, const uint8_t** base, uint64_t* size )
+{
+    *base = c->dIn;
+    *size = c->inSize;
+    const auto upload = c->upload;
+    if ( !upload || upload->total == 0 ) return MI355X_BZ2_OK;
+    needed = std::min( std::max<uint64_t>( needed, 1 ), upload->total );
+    hipEvent_t event = nullptr;
+    {
+        std::unique_lock lock( upload->mutex );
+        if ( ( upload->headBytes != 0 ) && ( needed <= upload->headBytes ) && ( upload->queued < needed ) ) {
+            upload->changed.wait( lock, [&] { return upload->failed || upload->headQueued; } );
+            *base = upload->head;
+            *size = upload->headBytes;
+            event = upload->headDone;
+        } else {
+            upload->changed.wait( lock, [&] { return upload->failed || upload->queued >= needed; } );
+            *base = upload->main;
+            *size = upload->total;
+            event = upload->done[( needed - 1 ) / InputUpload::PIECE];
+        }
+        if ( upload->failed ) {
+            c->lastError = "the streamed copy of the input failed";
+            return MI355X_BZ2_ERR_DEVICE;
+        }
+    }
+    HIP_TRY( c, hipStreamWaitEvent( c->stream, event, 0 ) );
+    return MI355X_BZ2_OK;
+}
+
+/** Reserve the ctx-owned input copy and queue `size` bytes into it (host or device source) on the ctx stream, zero padded;
+ * no wait.  Copies of more than 64 MiB from the host go in pieces, so that the first kernels of another context's batch
+ * are not queued behind one long transfer. */
+int
+queueInput( mi355x_bz2_ctx* c, const void* bytes, uint64_t size, hipMemcpyKind kind )
+{
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    c->upload.reset();
+    const int rc = reserveInput( c, size );
+    if ( rc != MI355X_BZ2_OK ) return rc;
+    const uint64_t padded = c->dInOwnedCapacity;
+    HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0,
+                                ( ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256 ) - ( size & ~uint64_t( 255 ) ), c->stream ) );
+    (void)padded;
     constexpr uint64_t PIECE = uint64_t( 64 ) << 20;
     for ( uint64_t at = 0; at < size; at += PIECE ) {
         HIP_TRY( c, hipMemcpyAsync( c->dInOwned + at, static_cast<const uint8_t*>( bytes ) + at, std::min( PIECE, size - at ),
@@ -457,6 +574,83 @@ mi355x_bz2_set_input_host_async( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64
 }
 
 int
+mi355x_bz2_set_input_host_streamed( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t size )
+{
+    if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "set_input_host_streamed: a batch is in flight";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    c->upload.reset();
+    (void)hipFree( c->dInOwned );      /* the streamed copy owns its buffers */
+    c->dInOwned = nullptr;
+    c->dInOwnedCapacity = 0;
+    auto upload = std::make_shared<InputUpload>();
+    upload->total = size;
+    upload->device = c->device;
+    HIP_TRY( c, hipStreamCreateWithFlags( &upload->stream, hipStreamNonBlocking ) );
+    upload->done.resize( (size_t)( ( size + InputUpload::PIECE - 1 ) / InputUpload::PIECE ), nullptr );
+    for ( auto& e : upload->done ) {
+        HIP_TRY( c, hipEventCreateWithFlags( &e, hipEventDisableTiming ) );
+    }
+    HIP_TRY( c, hipEventCreateWithFlags( &upload->headDone, hipEventDisableTiming ) );
+    const auto paddedSize = [] ( uint64_t n ) { return ( ( n + 255 ) & ~uint64_t( 255 ) ) + 256; };
+    if ( size > InputUpload::HEAD ) {
+        upload->headBytes = InputUpload::HEAD;
+        HIP_TRY( c, hipMalloc( &upload->head, paddedSize( upload->headBytes ) ) );
+    }
+    InputUpload* const u = upload.get();
+    upload->worker = std::thread( [u, bytes, size, paddedSize] () {
+        bool ok = hipSetDevice( u->device ) == hipSuccess;
+        if ( ok && u->headBytes != 0 ) {
+            ok = hipMemsetAsync( u->head + u->headBytes, 0, paddedSize( u->headBytes ) - u->headBytes, u->stream ) == hipSuccess
+                 && hipMemcpyAsync( u->head, bytes, u->headBytes, hipMemcpyHostToDevice, u->stream ) == hipSuccess
+                 && hipEventRecord( u->headDone, u->stream ) == hipSuccess;
+            const std::scoped_lock guard( u->mutex );
+            if ( ok ) u->headQueued = true; else u->failed = true;
+            u->changed.notify_all();
+        }
+        if ( ok ) {
+            uint8_t* buffer = nullptr;
+            ok = hipMalloc( &buffer, paddedSize( size ) ) == hipSuccess
+                 && hipMemsetAsync( buffer + ( size & ~uint64_t( 255 ) ), 0, paddedSize( size ) - ( size & ~uint64_t( 255 ) ), u->stream ) == hipSuccess;
+            const std::scoped_lock guard( u->mutex );
+            u->main = buffer;
+        }
+        for ( uint64_t at = 0, k = 0; ok && at < size; at += InputUpload::PIECE, ++k ) {
+            const uint64_t n = std::min( InputUpload::PIECE, size - at );
+            /* from pageable memory this call returns when the piece has been staged, i.e. the thread paces the copy */
+            ok = hipMemcpyAsync( u->main + at, bytes + at, n, hipMemcpyHostToDevice, u->stream ) == hipSuccess
+                 && hipEventRecord( u->done[k], u->stream ) == hipSuccess;
+            const std::scoped_lock guard( u->mutex );
+            if ( ok ) u->queued = at + n; else u->failed = true;
+            u->changed.notify_all();
+        }
+        if ( !ok ) {
+            const std::scoped_lock guard( u->mutex );
+            u->failed = true;
+            u->changed.notify_all();
+        }
+    } );
+    c->upload = std::move( upload );
+    c->dIn = nullptr;     /* set by the first call that needs the whole input (awaitInput gives the buffer to use) */
+    c->inSize = size;
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_input_resident( const mi355x_bz2_ctx* c )
+{
+    if ( c == nullptr ) return 0;
+    const auto upload = c->upload;
+    if ( !upload ) return c->dIn != nullptr ? 1 : 0;
+    const std::scoped_lock lock( upload->mutex );
+    return ( upload->failed || upload->queued >= upload->total ) ? 1 : 0;
+}
+
+int
 mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_t size )
 {
     if ( c == nullptr || ( deviceBytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
@@ -474,7 +668,7 @@ mi355x_bz2_share_input( mi355x_bz2_ctx* c, mi355x_bz2_ctx* from )
 {
     if ( c == nullptr || from == nullptr || c == from ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex, from->mutex );
-    if ( from->dIn == nullptr || c->device != from->device ) {
+    if ( ( from->dIn == nullptr && !from->upload ) || c->device != from->device ) {
         c->lastError = "share_input: the other context has no input or lives on another device";
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
@@ -484,6 +678,7 @@ mi355x_bz2_share_input( mi355x_bz2_ctx* c, mi355x_bz2_ctx* from )
     }
     c->dIn = from->dIn;      /* not owned: mi355x_bz2_destroy frees dInOwned only */
     c->inSize = from->inSize;
+    c->upload = from->upload;
     return MI355X_BZ2_OK;
 }
 
@@ -515,13 +710,23 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         c->lastError = "more than MI355X_BZ2_MAX_BATCH_BLOCKS blocks in one batch: split it";
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
-    if ( c->dIn == nullptr ) {
+    if ( c->dIn == nullptr && !c->upload ) {
         c->lastError = "no input set";
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
     HIP_TRY( c, hipSetDevice( c->device ) );
     int rc = ensureScratch( c, n );
     if ( rc != MI355X_BZ2_OK ) return rc;
+    /* with a streamed copy of the input this batch needs it up to where its last block can end (a block of 900 000
+     * symbols is at most 900 000 x 20 bits, in practice < 1.2 MB; the scan kernels read up to 256 B further) */
+    const uint8_t* inBase = nullptr;
+    uint64_t inSize = 0;
+    {
+        uint64_t last = 0;
+        for ( uint32_t i = 0; i < n; ++i ) last = std::max( last, offsets[i] );
+        rc = awaitInput( c, last / 8 + 2400000, &inBase, &inSize );
+        if ( rc != MI355X_BZ2_OK ) return rc;
+    }
 
     /* ---- plan: cost estimate, groups, slots, work order --------------------------------------------------------
      * cost = estimated compressed size (distance to the next requested offset, or to the end of the input).
@@ -544,7 +749,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         for ( uint32_t i = 0; i < n; ++i ) byOffset[i] = i;
         std::sort( byOffset.begin(), byOffset.end(), [&] ( uint32_t a, uint32_t b ) { return offsets[a] < offsets[b]; } );
         for ( uint32_t k = 0; k < n; ++k ) {
-            const uint64_t next = k + 1 < n ? offsets[byOffset[k + 1]] : c->inSize * 8;
+            const uint64_t next = k + 1 < n ? offsets[byOffset[k + 1]] : inSize * 8;
             const uint64_t cur = offsets[byOffset[k]];
             cost[byOffset[k]] = next > cur ? next - cur : 0;
         }
@@ -662,26 +867,26 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             /* wavefronts per block: one when the batch fills the GPU by itself, four or eight (speculative builds of
              * the next groups, see bz2_hscan.hip.h) when few blocks have to be through quickly */
             const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves : ( n <= 64 ? 8u : ( n <= 1280 ? 4u : 1u ) );
-            const auto* const inWords = reinterpret_cast<const uint32_t*>( c->dIn );
+            const auto* const inWords = reinterpret_cast<const uint32_t*>( inBase );
             if ( scanWaves >= 8 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             } else if ( scanWaves >= 4 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             } else if ( scanWaves >= 2 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             } else {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( m ), dim3( 64 ), 0, q, inWords, c->inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( m ), dim3( 64 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             }
             TIMED_LAUNCH( c, g, q, 13, k_hsym, dim3( ( MAX_SCAN_GROUPS + SYM_THREADS - 1 ) / SYM_THREADS, m ), dim3( SYM_THREADS ),
-                          0, q, reinterpret_cast<const uint32_t*>( c->dIn ), meta, hmeta, smeta, sel, htab, gpos, sym );
+                          0, q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym );
         } else {
             const uint32_t huffGrid = std::min( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES, g == expensiveGroup ? huffCapExpensive : huffCap );
             TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
-                          reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
+                          reinterpret_cast<const uint32_t*>( inBase ), inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
                           m, order );
         }
         TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
@@ -857,12 +1062,15 @@ mi355x_bz2_find_magic_device( mi355x_bz2_ctx* c, uint64_t magic48, uint64_t* bit
     }
     const std::scoped_lock lock( c->mutex );
     *nFound = 0;
-    if ( c->dIn == nullptr ) {
+    if ( c->dIn == nullptr && !c->upload ) {
         c->lastError = "no input set";
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
     if ( c->inSize < 6 ) return MI355X_BZ2_OK;
     HIP_TRY( c, hipSetDevice( c->device ) );
+    const uint8_t* inBase = nullptr;
+    uint64_t inSize = 0;
+    if ( const int rc = awaitInput( c, c->inSize, &inBase, &inSize ); rc != MI355X_BZ2_OK ) return rc;
     constexpr uint32_t CAP = 1u << 20;
     uint64_t* dFound = nullptr;
     uint32_t* dCounter = nullptr;
@@ -877,7 +1085,7 @@ mi355x_bz2_find_magic_device( mi355x_bz2_ctx* c, uint64_t magic48, uint64_t* bit
     do {
         if ( hipMemsetAsync( dCounter, 0, sizeof( uint32_t ), c->stream ) != hipSuccess ) { rc = MI355X_BZ2_ERR_DEVICE; break; }
         hipLaunchKernelGGL( k_find_magic, dim3( 4096 ), dim3( 256 ), 0, c->stream,
-                            reinterpret_cast<const uint32_t*>( c->dIn ), c->inSize * 8, magic48 & 0xFFFFFFFFFFFFULL,
+                            reinterpret_cast<const uint32_t*>( inBase ), inSize * 8, magic48 & 0xFFFFFFFFFFFFULL,
                             dFound, CAP, dCounter );
         if ( hipMemcpyAsync( &count, dCounter, sizeof( uint32_t ), hipMemcpyDeviceToHost, c->stream ) != hipSuccess
              || hipStreamSynchronize( c->stream ) != hipSuccess ) { rc = MI355X_BZ2_ERR_DEVICE; break; }

@@ -110,7 +110,7 @@ struct ScanShared
             uint8_t  lens[264];
             uint8_t  sym_to_byte[256];
         } build;
-        ScanSlot slot[2];   /* builds alternate between them */
+        ScanSlot slot[K > 1 ? 2 : 1];   /* K > 1: builds alternate between two, see k_hscan */
     };
 };
 
@@ -703,7 +703,7 @@ k_hscan( const uint32_t* __restrict__ in_words,
             }
             g += done;
             p += x >> 1;
-            which ^= 1u;
+            if ( K > 1 ) which ^= 1u;
             if ( stopAll ) break;
         }
         nGroups = g;

@@ -266,56 +266,60 @@ public:
             fail( MI355X_BZ2_ERR_STREAM_HEADER );
         }
         /* Several decoder contexts, each with its own submission thread: while one batch is copied to the host (and
-         * consumed), the next ones are being decoded.  They share ONE resident copy of the compressed file. */
+         * consumed), the next ones are being decoded.  They share ONE resident copy of the compressed file.  Only the first
+         * context is created here -- the first block goes to it at once; the others are created by their threads, beside
+         * the first launches (a context costs tens of milliseconds: streams, events, scratch). */
         const auto tCreate = std::chrono::steady_clock::now();
-        for ( size_t i = 0; i < m_contexts; ++i ) {
-            mi355x_bz2_config config{};
-            config.device = device;
-            /* scratch (13 MB per block) grows with the batches that are really launched: a reader that seeks and reads a
-             * little never pays for a full batch, a sequential one pays once per context, on that context's own thread */
-            config.max_batch_blocks = (uint32_t)std::min<size_t>( m_batch, 64 );
-            mi355x_bz2_ctx* ctx = nullptr;
-            int rc = mi355x_bz2_create( &config, &ctx );
+        m_ctxs.assign( m_contexts, nullptr );
+        {
             std::string detail;
-            if ( rc == MI355X_BZ2_OK ) {
-                rc = m_ctxs.empty() ? mi355x_bz2_set_input_host( ctx, m_source->bytes(), m_source->size() )
-                                    : mi355x_bz2_share_input( ctx, m_ctxs.front() );
-                if ( rc != MI355X_BZ2_OK ) {
-                    detail = mi355x_bz2_last_error( ctx );
-                    mi355x_bz2_destroy( ctx );
-                }
-            }
-            if ( rc != MI355X_BZ2_OK ) {
-                for ( auto* const c : m_ctxs ) mi355x_bz2_destroy( c );
-                m_ctxs.clear();
-                fail( rc, detail );
-            }
-            m_ctxs.push_back( ctx );
-        }
-        /* The file is resident on the GPU now: let it find the block magics too (k_find_magic, a few ms per GB); the
-         * host finder threads (about 1.3 GB/s of compressed data on eight cores) would pace the whole reader.  Same
-         * offsets, delivered at once; if the scan cannot be used (more matches than its result buffer holds) the host
-         * threads take over. */
-        const auto tInput = std::chrono::steady_clock::now();
-        if ( !m_finder->finalized() ) {
-            std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
-            uint64_t found = 0;
-            if ( ( mi355x_bz2_find_magic_device( m_ctxs.front(), MI355X_BZ2_MAGIC_BLOCK, offsets.data(), offsets.size(),
-                                                 &found ) == MI355X_BZ2_OK ) && ( found <= offsets.size() ) ) {
-                offsets.resize( found );
-                m_finder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
-            }
+            const int rc = createContext( device, nullptr, m_ctxs[0], detail );
+            if ( rc != MI355X_BZ2_OK ) fail( rc, detail );
         }
         if ( m_trace ) {
-            const auto now = std::chrono::steady_clock::now();
-            std::fprintf( stderr, "[reader] %zu contexts + %.0f MB resident: %.1f ms, magic scan: %.1f ms (%zu blocks)\n",
-                          m_ctxs.size(), m_source->size() / 1e6,
-                          std::chrono::duration<double, std::milli>( tInput - tCreate ).count(),
-                          std::chrono::duration<double, std::milli>( now - tInput ).count(), m_finder->size() );
+            std::fprintf( stderr, "[reader] first context, copy of %.0f MB started: %.1f ms\n", m_source->size() / 1e6,
+                          std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tCreate ).count() );
         }
-        for ( auto* const ctx : m_ctxs ) {
-            m_workers.emplace_back( [this, ctx] () { workerMain( ctx ); } );
+        scanOnDevice();
+        for ( size_t i = 0; i < m_contexts; ++i ) {
+            m_workers.emplace_back( [this, i, device] () {
+                if ( i > 0 ) {
+                    std::string detail;
+                    mi355x_bz2_ctx* ctx = nullptr;
+                    if ( createContext( device, m_ctxs[0], ctx, detail ) != MI355X_BZ2_OK ) {
+                        const std::scoped_lock lock( m_queueMutex );
+                        m_workerError = detail;
+                        return;   /* the others carry on */
+                    }
+                    m_ctxs[i] = ctx;
+                }
+                workerMain( m_ctxs[i] );
+            } );
         }
+    }
+
+    /** A decoder context over the file: the first one starts the copy to the GPU (in the background, in pieces: the first
+     * blocks decode while the rest of a large file is still on its way), the others share it. */
+    int
+    createContext( int device, mi355x_bz2_ctx* shareFrom, mi355x_bz2_ctx*& out, std::string& detail ) const
+    {
+        mi355x_bz2_config config{};
+        config.device = device;
+        /* scratch (13 MB per block) grows with the batches that are really launched: a reader that seeks and reads a
+         * little never pays for a full batch, a sequential one pays once per context, on that context's own thread */
+        config.max_batch_blocks = 1;
+        mi355x_bz2_ctx* ctx = nullptr;
+        int rc = mi355x_bz2_create( &config, &ctx );
+        if ( rc != MI355X_BZ2_OK ) return rc;
+        rc = shareFrom == nullptr ? mi355x_bz2_set_input_host_streamed( ctx, m_source->bytes(), m_source->size() )
+                                  : mi355x_bz2_share_input( ctx, shareFrom );
+        if ( rc != MI355X_BZ2_OK ) {
+            detail = mi355x_bz2_last_error( ctx );
+            mi355x_bz2_destroy( ctx );
+            return rc;
+        }
+        out = ctx;
+        return MI355X_BZ2_OK;
     }
 
     ~BatchScheduler()
@@ -329,7 +333,9 @@ public:
             if ( worker.joinable() ) worker.join();
         }
         m_flights.clear();
-        for ( auto it = m_ctxs.rbegin(); it != m_ctxs.rend(); ++it ) mi355x_bz2_destroy( *it );   /* owner of the input last */
+        for ( auto it = m_ctxs.rbegin(); it != m_ctxs.rend(); ++it ) {
+            if ( *it != nullptr ) mi355x_bz2_destroy( *it );   /* owner of the input last */
+        }
     }
 
     /** Decoder contexts for a batch size: a batch has a latency floor (its largest block), so smaller batches want more
@@ -390,6 +396,7 @@ public:
     demand( size_t block )
     {
         ++m_stats.gets;
+        scanOnDevice();
         collectFinished();
         m_pattern.note( block );
         if ( m_pattern.inOrder() ) {
@@ -463,6 +470,35 @@ private:
         return block - behind->first < behind->second.count ? behind : m_flights.end();
     }
 
+    /** Once the whole file is resident on the GPU: let it find the block magics too (k_find_magic, a few ms per GB); the
+     * host finder threads (about 1.3 GB/s of compressed data on eight cores), which serve the first blocks while the
+     * copy runs, would pace the whole reader.  Same offsets, delivered at once; if the scan cannot be used (more matches
+     * than its result buffer holds) the host threads carry on. */
+    void
+    scanOnDevice()
+    {
+        if ( m_scanned || m_finder->finalized() ) {
+            m_scanned = true;
+            return;
+        }
+        if ( mi355x_bz2_input_resident( m_ctxs.front() ) == 0 ) return;
+        m_scanned = true;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
+        uint64_t found = 0;
+        if ( ( mi355x_bz2_find_magic_device( m_ctxs.front(), MI355X_BZ2_MAGIC_BLOCK, offsets.data(), offsets.size(),
+                                             &found ) == MI355X_BZ2_OK ) && ( found <= offsets.size() ) ) {
+            offsets.resize( found );
+            m_finder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
+        }
+        if ( m_trace ) {
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf( stderr, "[reader] t=%.1f ms: file resident, magic scan %.1f ms (%zu blocks)\n",
+                          std::chrono::duration<double, std::milli>( now - m_created ).count(),
+                          std::chrono::duration<double, std::milli>( now - t0 ).count(), m_finder->size() );
+        }
+    }
+
     /** Launches whose worker is through move to the finished runs (one flag per launch is polled, not one future per
      * block: thousands of blocks can be in flight). */
     void
@@ -493,7 +529,7 @@ private:
     void
     launchAhead( size_t block, bool somebodyWaits )
     {
-        const size_t limit = m_batch * m_ctxs.size();        /* one full batch per context in flight */
+        const size_t limit = m_batch * m_contexts;           /* one full batch per context in flight */
         if ( m_inFlightBlocks >= limit ) return;
         /* While a launch is held back for want of blocks (rule at the end) a sequential reader gains about one candidate
          * per call: looking again on every call would cost O(batch^2) per batch. */
@@ -519,7 +555,9 @@ private:
         }
         /* as many as fit: a batch, the room in flight, the window of blocks decoded ahead (finished ones that are still
          * wanted must not be pushed out by newer ones, BlockFetcher.hpp:527-535) */
-        size_t room = std::min( { m_batch, limit - m_inFlightBlocks, end - from } );
+        /* the first launches are small and grow (64, 256, 1 024 blocks): a context's scratch for a full batch (13 MB per block)
+         * takes longer to allocate than the batch to decode, and the reader should not wait for that before its first bytes */
+        size_t room = std::min( { m_batch, limit - m_inFlightBlocks, end - from, m_ramp } );
         const size_t ahead = m_ready.blocksWithin( wanted.first, end ) + m_inFlightBlocks;
         room = ahead >= m_window ? 0 : std::min( room, m_window - ahead );
         std::vector<uint64_t> offsets;
@@ -536,7 +574,8 @@ private:
         /* A launch has a latency floor: go along with a launch somebody waits for, otherwise wait until half a batch
          * can go at once -- unless nothing is in flight at all. */
         const size_t worthIt = std::max<size_t>( 1, m_batch / 2 );
-        if ( somebodyWaits || ( offsets.size() >= worthIt ) || m_flights.empty() ) {
+        if ( somebodyWaits || ( offsets.size() >= std::min( worthIt, m_ramp ) ) || m_flights.empty() ) {
+            m_ramp = std::min( m_batch, 4 * m_ramp );
             m_stats.prefetches_submitted += offsets.size();
             launch( from, std::move( offsets ), /* urgent */ false, /* lookAhead */ true );
             m_holdOff = 0;
@@ -677,6 +716,8 @@ private:
     Flights m_flights;
     size_t m_inFlightBlocks{ 0 };
     size_t m_holdOff{ 0 };
+    size_t m_ramp{ 64 };         /* blocks of the next look-ahead launch while the reader is starting up */
+    bool m_scanned{ false };     /* the GPU has delivered the block offsets (or will not) */
 
     std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };
