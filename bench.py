@@ -134,7 +134,7 @@ def main():
                     help="round-1 mode: every rank decodes its own whole copy of the file (per-GPU work fixed)")
     ap.add_argument("--resident", action="store_true",
                     help="secondary figure only: compressed bytes already resident in HBM before the timed region")
-    ap.add_argument("--contexts", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--contexts", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="decoder contexts used in turn: step k+1 is queued on the next context before step k is "
                          "finished, so its transfer and its latency-bound first kernels overlap the kernels of step k.  "
                          "0 = 3 for one GPU (2 560 blocks per step keep the GPU busy; the third context hides the H2D "
@@ -220,6 +220,7 @@ def main():
         dist.all_gather_object(parts, (chain, n_blocks, my_decoded))
     else:
         parts = [(chain, n_blocks, my_decoded)]
+    extent_sizes = [p[2] for p in parts]
     if strong:
         stream_crc = combine_crc_chains((c, n) for c, n, _ in parts)
         assert sum(p[2] for p in parts) == file_decoded, (parts, file_decoded)
@@ -249,7 +250,8 @@ def main():
         mine = torch.as_tensor(_DevicePtr(decoder.output_device_ptr(), total), device="cuda")
         if args.backend == "gloo":
             mine = mine.cpu()
-        buf, _sizes = gather_extents(mine, rank, world, gather_buf)
+        # the sizes are those of the correctness pass (exchanged once): no size exchange, no host sync per step
+        buf, _sizes = gather_extents(mine, rank, world, gather_buf, sizes=extent_sizes if strong else None)
         if rank == 0:
             gather_buf = buf
         if args.backend == "nccl":

@@ -70,7 +70,7 @@ public:
     uint64_t
     append( uint64_t bits, uint64_t bitLength, uint64_t byteLength )
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         if ( m_sealed ) {
             throw std::invalid_argument( "the block index is complete: nothing can be appended" );
         }
@@ -102,7 +102,7 @@ public:
     [[nodiscard]] Span
     locate( uint64_t byteOffset ) const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         const auto behind = std::upper_bound( m_bytes.begin(), m_bytes.end(), byteOffset );
         if ( behind == m_bytes.begin() ) {
             return {};
@@ -114,7 +114,7 @@ public:
     [[nodiscard]] uint64_t
     frontier() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         return m_bytes.empty() ? 0 : m_bytes.back() + m_openBytes;
     }
 
@@ -122,7 +122,7 @@ public:
     [[nodiscard]] size_t
     dataBlocks() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         return m_bits.size() - m_emptyBlocks;
     }
 
@@ -130,7 +130,7 @@ public:
     void
     seal()
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         if ( m_sealed ) {
             return;
         }
@@ -148,7 +148,7 @@ public:
     [[nodiscard]] bool
     sealed() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         return m_sealed;
     }
 
@@ -157,7 +157,7 @@ public:
     void
     assign( const Pairs& sortedPairs )
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         m_bits.clear();
         m_bytes.clear();
         m_bits.reserve( sortedPairs.size() );
@@ -177,7 +177,7 @@ public:
     [[nodiscard]] Pairs
     snapshot() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         Pairs result( m_bits.size() );
         for ( size_t i = 0; i < m_bits.size(); ++i ) {
             result[i] = { m_bits[i], m_bytes[i] };
@@ -188,7 +188,7 @@ public:
     [[nodiscard]] std::pair<uint64_t, uint64_t>
     last() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         if ( m_bits.empty() ) {
             throw std::out_of_range( "the block index is empty" );
         }
@@ -198,7 +198,7 @@ public:
     [[nodiscard]] bool
     empty() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         return m_bits.empty();
     }
 
@@ -223,7 +223,7 @@ private:
         return span;
     }
 
-    mutable std::mutex m_mutex;
+    mutable std::mutex m_lock;
     std::vector<uint64_t> m_bits, m_bytes;          /* sorted; m_bytes non-decreasing */
     uint64_t m_openBits{ 0 }, m_openBytes{ 0 };     /* size of the last block while the index is still growing */
     size_t m_emptyBlocks{ 0 };
@@ -492,7 +492,7 @@ public:
     void
     startThreads()
     {
-        const std::scoped_lock lock( m_threadMutex );
+        const std::lock_guard<std::mutex> hold( m_threadLock );
         if ( !m_thread.joinable() && !m_finalized ) {
             m_cancel = false;
             m_thread = std::thread( [this] () { finderMain(); } );
@@ -503,11 +503,11 @@ public:
     stopThreads()
     {
         {
-            const std::scoped_lock lock( m_mutex );
+            const std::lock_guard<std::mutex> hold( m_lock );
             m_cancel = true;
-            m_changed.notify_all();
+            m_wake.notify_all();
         }
-        const std::scoped_lock lock( m_threadMutex );
+        const std::lock_guard<std::mutex> hold( m_threadLock );
         if ( m_thread.joinable() ) {
             m_thread.join();
         }
@@ -516,7 +516,7 @@ public:
     [[nodiscard]] size_t
     size() const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         return m_offsets.size();
     }
 
@@ -525,7 +525,7 @@ public:
     finalize( std::optional<size_t> blockCount = {} )
     {
         stopThreads();
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         if ( blockCount ) {
             if ( *blockCount > m_offsets.size() ) {
                 throw std::invalid_argument( "You may not finalize to a size larger than the current results buffer!" );
@@ -533,7 +533,7 @@ public:
             m_offsets.resize( *blockCount );
         }
         m_finalized = true;
-        m_changed.notify_all();
+        m_wake.notify_all();
     }
 
     [[nodiscard]] bool
@@ -549,15 +549,15 @@ public:
         if ( !m_finalized ) {
             startThreads();
         }
-        std::unique_lock lock( m_mutex );
+        std::unique_lock<std::mutex> hold( m_lock );
         m_highestRequested = std::max( m_highestRequested, blockNumber );
-        m_changed.notify_all();
+        m_wake.notify_all();
         if ( timeoutInSeconds > 0 ) {
             const auto predicate = [&] () { return m_finalized.load() || ( blockNumber < m_offsets.size() ); };
             if ( std::isfinite( timeoutInSeconds ) ) {
-                m_changed.wait_for( lock, std::chrono::nanoseconds( (int64_t)( timeoutInSeconds * 1e9 ) ), predicate );
+                m_wake.wait_for( hold, std::chrono::nanoseconds( (int64_t)( timeoutInSeconds * 1e9 ) ), predicate );
             } else {
-                m_changed.wait( lock, predicate );
+                m_wake.wait( hold, predicate );
             }
         }
         if ( blockNumber < m_offsets.size() ) {
@@ -570,7 +570,7 @@ public:
     [[nodiscard]] size_t
     find( size_t encodedBlockOffsetInBits ) const
     {
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         const auto match = std::lower_bound( m_offsets.begin(), m_offsets.end(), encodedBlockOffsetInBits );
         if ( ( match == m_offsets.end() ) || ( *match != encodedBlockOffsetInBits ) ) {
             throw std::out_of_range( "No block with the specified offset exists in the block finder map!" );
@@ -583,10 +583,10 @@ public:
     setBlockOffsets( std::deque<size_t> offsets )
     {
         stopThreads();
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         m_offsets = std::move( offsets );
         m_finalized = true;
-        m_changed.notify_all();
+        m_wake.notify_all();
     }
 
 private:
@@ -597,13 +597,13 @@ private:
         constexpr uint64_t CHUNK = 8u << 20;
         uint64_t position = 0;
         {
-            const std::scoped_lock lock( m_mutex );
+            const std::lock_guard<std::mutex> hold( m_lock );
             position = m_scanPosition;
         }
         while ( true ) {
             {
-                std::unique_lock lock( m_mutex );
-                m_changed.wait( lock, [this] {
+                std::unique_lock<std::mutex> hold( m_lock );
+                m_wake.wait( hold, [this] {
                     return m_cancel || ( m_offsets.size() <= m_highestRequested + m_prefetchCount );
                 } );
                 if ( m_cancel ) {
@@ -634,19 +634,19 @@ private:
             }
             position = end;
             {
-                const std::scoped_lock lock( m_mutex );
+                const std::lock_guard<std::mutex> hold( m_lock );
                 for ( const auto& part : parts ) {
                     for ( const auto offset : part ) {
                         m_offsets.push_back( offset );
                     }
                 }
-                m_changed.notify_all();
+                m_wake.notify_all();
             }
         }
-        const std::scoped_lock lock( m_mutex );
+        const std::lock_guard<std::mutex> hold( m_lock );
         m_scanPosition = position;
         m_finalized = true;
-        m_changed.notify_all();
+        m_wake.notify_all();
     }
 
     const uint8_t* const m_bytes;
@@ -655,15 +655,15 @@ private:
     const size_t m_prefetchCount;
     const unsigned m_scanThreads;
 
-    mutable std::mutex m_mutex;
-    std::condition_variable m_changed;
+    mutable std::mutex m_lock;
+    std::condition_variable m_wake;
     std::deque<size_t> m_offsets;
     size_t m_highestRequested{ 0 };
     uint64_t m_scanPosition{ 0 };
     std::atomic<bool> m_finalized{ false };
     bool m_cancel{ false };
 
-    std::mutex m_threadMutex;
+    std::mutex m_threadLock;
     std::thread m_thread;
 };
 }  // namespace mi355x

@@ -68,17 +68,21 @@ def combine_crc_chains(parts):
     return total
 
 
-def gather_extents(mine, rank, world, out=None):
+def gather_extents(mine, rank, world, out=None, sizes=None):
     """Gather ragged 1-D uint8 tensors (one decoded extent per rank) into rank 0, in rank order.
 
     Returns (buffer, sizes) on rank 0 -- buffer holds the extents of ranks 1..world-1 back to back (rank 0's own
-    extent stays where it is) -- and (None, sizes) elsewhere.  `out` may be a preallocated receive buffer."""
+    extent stays where it is) -- and (None, sizes) elsewhere.  `out` may be a preallocated receive buffer.  `sizes`: the
+    extent sizes of all ranks if the caller knows them already (the same file decoded again: the exchange of sizes and
+    the host synchronization that reading them costs are skipped)."""
     if world == 1:
         return None, [int(mine.numel())]
     device = mine.device
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=device))
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=device))
+        sizes = [int(s.item()) for s in sizes]
+    assert sizes[rank] == mine.numel()
     if rank == 0:
         need = sum(sizes[1:])
         if out is None or out.numel() < need:
