@@ -831,6 +831,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     const bool useScan = !( hm != nullptr && std::strcmp( hm, "window" ) == 0 );
     const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: wavefronts per block in k_hscan (1, 2, 4, 8) */
     const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;
+    /* 1: k_hscan_pc (producer + consumer wave) where one wave per block is chosen.  Measured slower than k_hscan<1>
+     * (DESIGN.md section 4): both are bound by instruction issue, and the pair does ~25 % more of it */
+    const char* spc = std::getenv( "MI355X_BZ2_SCAN_PC" );
+    const bool scanPc = spc != nullptr && spc[0] == '1';
     const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
     const uint32_t scanTune = st != nullptr ? (uint32_t)std::atoi( st ) : 0u;
     const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
@@ -877,6 +881,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             } else if ( scanWaves >= 2 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            } else if ( scanPc ) {
+                /* one block per workgroup, producer + consumer wave (k_hscan_pc) */
+                TIMED_LAUNCH( c, g, q, 12, k_hscan_pc, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order );
             } else {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( m ), dim3( 64 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );

@@ -364,16 +364,18 @@ def bench_slice(native):
     return _slice["v"]
 
 
-@pytest.mark.parametrize("variant", ["scan-1", "scan-2", "scan-4", "scan-8", "window"])
+@pytest.mark.parametrize("variant", ["scan-pc", "scan-1", "scan-2", "scan-4", "scan-8", "window"])
 def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
-    """Every form of the Huffman stage -- k_hscan with 1, 2, 4 or 8 wavefronts per block (+ k_hsym) and the single-chain
+    """Every form of the Huffman stage -- k_hscan_pc, k_hscan with 1, 2, 4 or 8 wavefronts per block (+ k_hsym) and the single-chain
     k_huff -- against the oracle, whatever the batch size would select by itself: valid data of all kinds, streams no
     libbz2 writes, one invalid stream per reference throw site, and seeded damage (every field of every record)."""
     if variant == "window":
         monkeypatch.setenv("MI355X_BZ2_HUFF", "window")
     else:
+        # scan-pc: producer + consumer wave per block (k_hscan_pc), scan-N: N cooperating waves (k_hscan<N>)
         monkeypatch.setenv("MI355X_BZ2_HUFF", "scan")
-        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", variant.split("-")[1])
+        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1" if variant == "scan-pc" else variant.split("-")[1])
+        monkeypatch.setenv("MI355X_BZ2_SCAN_PC", "1" if variant == "scan-pc" else "0")
     d = native.Decoder(flags=native.Decoder.KEEP_STAGES)
     try:
         corpus = datagen.corpus_small()
