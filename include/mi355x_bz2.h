@@ -117,6 +117,11 @@ const char* mi355x_bz2_kernel_name( uint32_t index );
 /* Create / destroy a decoder context bound to one GPU and one HIP stream.
  * Fails with MI355X_BZ2_ERR_NO_DEVICE when no usable gfx950 device exists: there is no CPU fallback. */
 int  mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** ctx );
+/* Optional: pay the one-time cost of the HIP runtime and of loading this library's kernels (0.2 s per process, otherwise
+ * part of the first mi355x_bz2_create / the first launch) at a moment of the caller's choosing, e.g. on a thread while
+ * the application starts.  No reference counterpart (the reference's thread pool starts lazily too, BlockFetcher.hpp:620);
+ * never needed for correctness.  Do not call it in a process that forks workers afterwards. */
+int  mi355x_bz2_warmup( int32_t device );
 void mi355x_bz2_destroy( mi355x_bz2_ctx* ctx );
 const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
 
@@ -172,6 +177,14 @@ int mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* ctx, mi355x_bz2_block_result* r
 const void* mi355x_bz2_output_device( const mi355x_bz2_ctx* ctx );
 /* Copy [offset, offset+size) of the last batch's output to host memory (D2H). */
 int mi355x_bz2_copy_output( mi355x_bz2_ctx* ctx, uint64_t offset, uint64_t size, void* host_dst );
+/* The same copy in the background, on a stream of its own: _begin (after decode_batch_end, before the next
+ * decode_batch_begin) queues it and returns, _end waits for the copy started last.  The context then writes its next
+ * batch into a second output buffer, so the next decode_batch_begin may follow at once: the copy of batch k overlaps the
+ * kernels of batch k + 1 (the reader's per-context loop; ParallelBZ2Reader gets the same overlap from its thread pool,
+ * BlockFetcher.hpp:620-642).  `host_dst` should be page-locked and must stay valid until _end has returned.
+ * mi355x_bz2_output_device keeps pointing at the batch finished last. */
+int mi355x_bz2_copy_output_begin( mi355x_bz2_ctx* ctx, uint64_t offset, uint64_t size, void* host_dst );
+int mi355x_bz2_copy_output_end( mi355x_bz2_ctx* ctx );
 int mi355x_bz2_last_timings( const mi355x_bz2_ctx* ctx, mi355x_bz2_timings* timings );
 /* Only the duration of the last batch's kernel pipeline (HIP events before the first and after the last kernel): one
  * event query instead of the ~90 that the per-kernel breakdown of mi355x_bz2_last_timings needs. */

@@ -11,6 +11,9 @@ import os as _os
 # reads this when it starts, so it only helps if nothing has touched the GPU yet; an existing setting wins)
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from ._native import Bz2Error, Decoder, find_magic, lib, status_string  # noqa: F401
+from ._native import Bz2Error, Decoder, find_magic, lib, status_string, warmup  # noqa: F401
 from .reader import (IndexedBzip2File, IndexedBzip2FileRaw, open, read_block_offsets,  # noqa: F401
                      write_block_offsets)
+
+if _os.environ.get("MI355X_BZ2_WARMUP") == "1":     # opt-in: see warmup()
+    warmup()

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("mi355x_bz2_status_string", ctypes.c_char_p, [ctypes.c_int]),
     ("mi355x_bz2_abi_version", ctypes.c_int, []),
     ("mi355x_bz2_create", ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
+    ("mi355x_bz2_warmup", ctypes.c_int, [ctypes.c_int32]),
     ("mi355x_bz2_destroy", None, [_vp]),
     ("mi355x_bz2_last_error", ctypes.c_char_p, [_vp]),
     ("mi355x_bz2_set_input_host", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64]),
@@ -100,6 +101,8 @@ SYMBOLS = [
     ("mi355x_bz2_decode_batch_end", ctypes.c_int, [_vp, ctypes.POINTER(BlockResult), _u64p]),
     ("mi355x_bz2_output_device", _vp, [_vp]),
     ("mi355x_bz2_copy_output", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    ("mi355x_bz2_copy_output_begin", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    ("mi355x_bz2_copy_output_end", ctypes.c_int, [_vp]),
     ("mi355x_bz2_last_timings", ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     ("mi355x_bz2_last_pipeline_ms", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     ("mi355x_bz2_kernel_name", ctypes.c_char_p, [ctypes.c_uint32]),
@@ -154,6 +157,21 @@ def lib():
             fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+def warmup(device: int = 0, background: bool = True):
+    """Start the HIP runtime and load the kernels now (0.2 s once per process) instead of inside the first open():
+    on a daemon thread by default, so the caller carries on.  Optional; not for processes that fork workers later."""
+    L = lib()
+    if not background:
+        rc = L.mi355x_bz2_warmup(device)
+        if rc != 0:
+            raise Bz2Error(rc)
+        return None
+    import threading
+    thread = threading.Thread(target=L.mi355x_bz2_warmup, args=(device,), daemon=True)
+    thread.start()
+    return thread
 
 
 def status_string(status: int) -> str:
@@ -287,6 +305,15 @@ class Decoder:
 
     def stream_ptr(self) -> int:
         return lib().mi355x_bz2_stream(self._h) or 0
+
+    def copy_output_begin(self, offset: int, size: int):
+        """Background D2H of the last batch's bytes; returns the ctypes buffer, valid after copy_output_end()."""
+        buf = (ctypes.c_ubyte * max(1, size))()
+        self._check(lib().mi355x_bz2_copy_output_begin(self._h, offset, size, buf))
+        return buf
+
+    def copy_output_end(self):
+        self._check(lib().mi355x_bz2_copy_output_end(self._h))
 
     def copy_output(self, offset: int, size: int) -> bytes:
         buf = ctypes.create_string_buffer(max(1, size))

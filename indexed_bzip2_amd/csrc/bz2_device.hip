@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -90,8 +91,21 @@ struct mi355x_bz2_ctx
     uint64_t inSize{ 0 };
     std::shared_ptr<InputUpload> upload;   /* set while / after a streamed copy of the input */
 
+    /* Buffers that have been replaced by larger ones.  hipFree / hipHostFree wait for the whole device, i.e. for the
+     * batches of every other context: a growing buffer is put aside instead and freed when the context goes, or when
+     * what has been put aside outweighs what is in use (then the wait is paid once, see retire). */
+    struct Retired
+    {
+        void* pointer{ nullptr };
+        uint64_t bytes{ 0 };
+        bool host{ false };
+    };
+    std::vector<Retired> retired;
+    uint64_t retiredBytes{ 0 };
+
     /* per-block scratch, capacity in blocks: one device and one page-locked host allocation, carved up by ensureScratch */
     uint32_t capacity{ 0 };
+    uint64_t scratchBytes{ 0 }, scratchHostBytes{ 0 };
     uint8_t* dScratch{ nullptr };
     uint8_t* hScratch{ nullptr };
     uint64_t* dOffsets{ nullptr };
@@ -121,9 +135,29 @@ struct mi355x_bz2_ctx
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
 
-    /* output */
-    uint8_t* dOut{ nullptr };
-    uint64_t outCapacity{ 0 };
+    /* output: dOut holds the last finished batch.  A caller that copies it out in the background
+     * (mi355x_bz2_copy_output_begin) gets the next batch written into a second buffer, so that the copy and the next
+     * decode overlap; callers that never do keep a single buffer. */
+    struct OutBuffer
+    {
+        uint8_t* bytes{ nullptr };
+        uint64_t capacity{ 0 };
+        hipEvent_t copied{ nullptr };     /* behind the last background copy out of this buffer */
+        bool copyIssued{ false };
+    };
+    OutBuffer out[2];
+    int outCurrent{ 0 };
+    int outLastCopy{ 0 };
+    hipStream_t copyStream{ nullptr };
+    uint8_t* dOut{ nullptr };             /* == out[outCurrent].bytes */
+
+    /* mi355x_bz2_find_magic_device: a stream and buffers of its own, so that a scan neither queues behind a batch nor
+     * stops one (hipFree waits for the whole device) */
+    std::mutex scanMutex;
+    hipStream_t scanStream{ nullptr };
+    hipEvent_t scanOrder{ nullptr };
+    uint64_t* dScanFound{ nullptr };
+    uint32_t* dScanCounter{ nullptr };
     uint64_t outSize{ 0 };
     uint32_t lastBlocks{ 0 };
 
@@ -190,10 +224,39 @@ initCrcConsts( CrcConsts& cc )
     } while ( 0 )
 
 void
-freeScratch( mi355x_bz2_ctx* c )
+freeRetired( mi355x_bz2_ctx* c )
 {
-    (void)hipFree( c->dScratch ); c->dScratch = nullptr;
-    (void)hipHostFree( c->hScratch ); c->hScratch = nullptr;
+    for ( const auto& r : c->retired ) {
+        if ( r.host ) (void)hipHostFree( r.pointer ); else (void)hipFree( r.pointer );
+    }
+    c->retired.clear();
+    c->retiredBytes = 0;
+}
+
+/** Puts a buffer that is no longer used aside (nothing on the device may still be reading it: the caller has
+ * synchronised the streams that did). */
+void
+retire( mi355x_bz2_ctx* c, void* pointer, uint64_t bytes, bool host, uint64_t inUseNow )
+{
+    if ( pointer == nullptr ) return;
+    c->retired.push_back( { pointer, bytes, host } );
+    c->retiredBytes += bytes;
+    if ( c->retiredBytes > std::max<uint64_t>( inUseNow, uint64_t( 1 ) << 30 ) ) freeRetired( c );
+}
+
+void
+freeScratch( mi355x_bz2_ctx* c, bool now = true )
+{
+    if ( now ) {
+        (void)hipFree( c->dScratch );
+        (void)hipHostFree( c->hScratch );
+    } else {
+        retire( c, c->dScratch, c->scratchBytes, false, c->scratchBytes );
+        retire( c, c->hScratch, c->scratchHostBytes, true, c->scratchBytes );
+    }
+    c->dScratch = nullptr;
+    c->hScratch = nullptr;
+    c->scratchBytes = c->scratchHostBytes = 0;
     c->dOffsets = nullptr; c->dOrder = nullptr; c->dMeta = nullptr; c->dSel = nullptr; c->dSym = nullptr; c->dStb = nullptr;
     c->dHmeta = nullptr; c->dSmeta = nullptr; c->dHtab = nullptr; c->dGpos = nullptr; c->dL = nullptr; c->dTab = nullptr;
     c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegOff = nullptr; c->dSegCont = nullptr;
@@ -209,7 +272,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
 {
     if ( nBlocks <= c->capacity ) return MI355X_BZ2_OK;
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
-    freeScratch( c );
+    freeScratch( c, /* now */ false );
     /* about 13 MB of scratch per block: powers of two while that is cheap, multiples of 256 blocks beyond */
     uint32_t cap = 8;
     while ( cap < nBlocks && cap < 512 ) cap *= 2;
@@ -248,8 +311,13 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t hMetaAt = reserve( hostBytes, (size_t)cap * sizeof( BlockMeta ) );
     const size_t hOffsetsAt = reserve( hostBytes, (size_t)cap * sizeof( uint64_t ) );
 
+    const auto tAlloc = std::chrono::steady_clock::now();
     HIP_TRY( c, hipMalloc( &c->dScratch, deviceBytes ) );
     HIP_TRY( c, hipHostMalloc( &c->hScratch, hostBytes, hipHostMallocDefault ) );
+    if ( std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr ) {
+        std::fprintf( stderr, "[device] scratch for %u blocks (%.0f MB): %.1f ms\n", cap, deviceBytes / 1e6,
+                      std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tAlloc ).count() );
+    }
     uint8_t* const d = c->dScratch;
     uint8_t* const h = c->hScratch;
     c->dOffsets = reinterpret_cast<uint64_t*>( d + oOffsets );
@@ -279,20 +347,35 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->hMeta = reinterpret_cast<BlockMeta*>( h + hMetaAt );
     c->hOffsets = reinterpret_cast<uint64_t*>( h + hOffsetsAt );
     c->capacity = cap;
+    c->scratchBytes = deviceBytes;
+    c->scratchHostBytes = hostBytes;
     return MI355X_BZ2_OK;
 }
 
+/** The buffer the batch that is being finished writes its `size` bytes to: the other one if the last batch's bytes are
+ * (or may still be) on their way to the host in the background, else the same again.  Kernels queued on c->stream behind
+ * this call wait for the copy that last read from the chosen buffer. */
 int
 ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 {
-    if ( size + 256 <= c->outCapacity ) return MI355X_BZ2_OK;
-    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
-    (void)hipFree( c->dOut );
-    c->dOut = nullptr;
-    c->outCapacity = 0;
-    uint64_t cap = size + size / 8 + ( 1u << 20 );
-    HIP_TRY( c, hipMalloc( &c->dOut, cap ) );
-    c->outCapacity = cap;
+    const int target = c->out[c->outCurrent].copyIssued ? c->outCurrent ^ 1 : c->outCurrent;
+    auto& buffer = c->out[target];
+    if ( buffer.copyIssued ) {
+        HIP_TRY( c, hipStreamWaitEvent( c->stream, buffer.copied, 0 ) );
+    }
+    if ( size + 256 > buffer.capacity ) {
+        HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+        if ( buffer.copyIssued ) HIP_TRY( c, hipEventSynchronize( buffer.copied ) );
+        retire( c, buffer.bytes, buffer.capacity, false, size );
+        buffer.bytes = nullptr;
+        buffer.capacity = 0;
+        const uint64_t cap = size + size / 8 + ( 1u << 20 );
+        HIP_TRY( c, hipMalloc( &buffer.bytes, cap ) );
+        buffer.capacity = cap;
+    }
+    buffer.copyIssued = false;
+    c->outCurrent = target;
+    c->dOut = buffer.bytes;
     return MI355X_BZ2_OK;
 }
 }  // namespace
@@ -362,6 +445,23 @@ int
 mi355x_bz2_abi_version( void )
 {
     return MI355X_BZ2_ABI_VERSION;
+}
+
+int
+mi355x_bz2_warmup( int32_t device )
+{
+    int count = 0;
+    if ( hipGetDeviceCount( &count ) != hipSuccess || count <= 0 ) return MI355X_BZ2_ERR_NO_DEVICE;
+    if ( device < 0 || device >= count ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    if ( hipSetDevice( device ) != hipSuccess ) return MI355X_BZ2_ERR_DEVICE;
+    /* the runtime's queues and the code object of this library: an empty magic scan is the cheapest real launch */
+    uint32_t* counter = nullptr;
+    if ( hipMalloc( &counter, 256 ) != hipSuccess ) return MI355X_BZ2_ERR_DEVICE;
+    hipLaunchKernelGGL( k_find_magic, dim3( 1 ), dim3( 256 ), 0, nullptr, reinterpret_cast<const uint32_t*>( counter ),
+                        uint64_t( 0 ), MI355X_BZ2_MAGIC_BLOCK, reinterpret_cast<uint64_t*>( counter ), 0u, counter );
+    const bool ok = hipDeviceSynchronize() == hipSuccess;
+    (void)hipFree( counter );
+    return ok ? MI355X_BZ2_OK : MI355X_BZ2_ERR_DEVICE;
 }
 
 int
@@ -446,9 +546,22 @@ mi355x_bz2_destroy( mi355x_bz2_ctx* c )
         if ( c->gstream[g] ) (void)hipStreamSynchronize( c->gstream[g] );
     }
     freeScratch( c );
+    freeRetired( c );
     c->upload.reset();   /* joins the copy thread (of the owner; sharers only drop their reference) before the memory goes */
     (void)hipFree( c->dInOwned );
-    (void)hipFree( c->dOut );
+    if ( c->scanStream ) {
+        (void)hipStreamSynchronize( c->scanStream );
+        (void)hipStreamDestroy( c->scanStream );
+    }
+    if ( c->scanOrder ) (void)hipEventDestroy( c->scanOrder );
+    (void)hipFree( c->dScanFound );
+    (void)hipFree( c->dScanCounter );
+    if ( c->copyStream ) (void)hipStreamSynchronize( c->copyStream );
+    for ( auto& buffer : c->out ) {
+        (void)hipFree( buffer.bytes );
+        if ( buffer.copied ) (void)hipEventDestroy( buffer.copied );
+    }
+    if ( c->copyStream ) (void)hipStreamDestroy( c->copyStream );
     for ( auto& group : c->ev ) {
         for ( auto& e : group ) {
             if ( e ) (void)hipEventDestroy( e );
@@ -619,8 +732,14 @@ mi355x_bz2_set_input_host_streamed( mi355x_bz2_ctx* c, const uint8_t* bytes, uin
             const std::scoped_lock guard( u->mutex );
             u->main = buffer;
         }
+        const bool traceUpload = std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr;
+        const auto tUpload = std::chrono::steady_clock::now();
         for ( uint64_t at = 0, k = 0; ok && at < size; at += InputUpload::PIECE, ++k ) {
             const uint64_t n = std::min( InputUpload::PIECE, size - at );
+            if ( traceUpload && k % 16 == 0 ) {
+                std::fprintf( stderr, "[device] upload at %.0f MB: %.1f ms\n", at / 1e6,
+                              std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tUpload ).count() );
+            }
             /* from pageable memory this call returns when the piece has been staged, i.e. the thread paces the copy */
             ok = hipMemcpyAsync( u->main + at, bytes + at, n, hipMemcpyHostToDevice, u->stream ) == hipSuccess
                  && hipEventRecord( u->done[k], u->stream ) == hipSuccess;
@@ -715,8 +834,11 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
     HIP_TRY( c, hipSetDevice( c->device ) );
+    const bool traceBegin = std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr;
+    const auto tBegin = std::chrono::steady_clock::now();
     int rc = ensureScratch( c, n );
     if ( rc != MI355X_BZ2_OK ) return rc;
+    const auto tScratch = std::chrono::steady_clock::now();
     /* with a streamed copy of the input this batch needs it up to where its last block can end (a block of 900 000
      * symbols is at most 900 000 x 20 bits, in practice < 1.2 MB; the scan kernels read up to 256 B further) */
     const uint8_t* inBase = nullptr;
@@ -727,6 +849,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         rc = awaitInput( c, last / 8 + 2400000, &inBase, &inSize );
         if ( rc != MI355X_BZ2_OK ) return rc;
     }
+    const auto tInput = std::chrono::steady_clock::now();
 
     /* ---- plan: cost estimate, groups, slots, work order --------------------------------------------------------
      * cost = estimated compressed size (distance to the next requested offset, or to the end of the input).
@@ -923,6 +1046,11 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     c->pendingGroups = nGroups;
     c->pendingExpensive = expensiveGroup;
     for ( int g = 0; g < MAX_GROUPS; ++g ) c->pendingGroupCount[g] = groupCount[g];
+    if ( traceBegin ) {
+        const auto ms = [] ( auto a, auto b ) { return std::chrono::duration<double, std::milli>( b - a ).count(); };
+        std::fprintf( stderr, "[device] begin of %u blocks: scratch %.1f ms, input %.1f ms, plan + launches %.1f ms\n", n,
+                      ms( tBegin, tScratch ), ms( tScratch, tInput ), ms( tInput, std::chrono::steady_clock::now() ) );
+    }
     return MI355X_BZ2_OK;
 }
 
@@ -1026,6 +1154,42 @@ mi355x_bz2_copy_output( mi355x_bz2_ctx* c, uint64_t offset, uint64_t size, void*
 }
 
 int
+mi355x_bz2_copy_output_begin( mi355x_bz2_ctx* c, uint64_t offset, uint64_t size, void* hostDst )
+{
+    if ( c == nullptr || ( hostDst == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( offset + size > c->outSize || c->pendingBlocks != 0 ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    auto& buffer = c->out[c->outCurrent];
+    if ( c->copyStream == nullptr ) HIP_TRY( c, hipStreamCreateWithFlags( &c->copyStream, hipStreamNonBlocking ) );
+    if ( buffer.copied == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &buffer.copied, hipEventDisableTiming ) );
+    /* decode_batch_end has synchronised c->stream: the bytes are there */
+    if ( size > 0 ) HIP_TRY( c, hipMemcpyAsync( hostDst, buffer.bytes + offset, size, hipMemcpyDeviceToHost, c->copyStream ) );
+    HIP_TRY( c, hipEventRecord( buffer.copied, c->copyStream ) );
+    buffer.copyIssued = true;
+    c->outLastCopy = c->outCurrent;
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_copy_output_end( mi355x_bz2_ctx* c )
+{
+    if ( c == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    hipEvent_t event = nullptr;
+    {
+        const std::scoped_lock lock( c->mutex );
+        event = c->out[c->outLastCopy].copied;
+    }
+    if ( event == nullptr ) return MI355X_BZ2_OK;   /* no background copy was ever started */
+    if ( hipEventSynchronize( event ) != hipSuccess ) {
+        const std::scoped_lock lock( c->mutex );
+        c->lastError = "hipEventSynchronize( copied ) failed";
+        return MI355X_BZ2_ERR_DEVICE;
+    }
+    return MI355X_BZ2_OK;
+}
+
+int
 mi355x_bz2_last_timings( const mi355x_bz2_ctx* c, mi355x_bz2_timings* t )
 {
     if ( c == nullptr || t == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
@@ -1068,49 +1232,68 @@ mi355x_bz2_find_magic_device( mi355x_bz2_ctx* c, uint64_t magic48, uint64_t* bit
     if ( c == nullptr || nFound == nullptr || ( capacity > 0 && bitOffsets == nullptr ) ) {
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
-    const std::scoped_lock lock( c->mutex );
     *nFound = 0;
-    if ( c->dIn == nullptr && !c->upload ) {
-        c->lastError = "no input set";
-        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
-    }
-    if ( c->inSize < 6 ) return MI355X_BZ2_OK;
-    HIP_TRY( c, hipSetDevice( c->device ) );
+    constexpr uint32_t CAP = 1u << 20;
+    const std::scoped_lock scanLock( c->scanMutex );   /* one scan at a time per context: they share the buffers below */
+    std::shared_ptr<InputUpload> upload;
     const uint8_t* inBase = nullptr;
     uint64_t inSize = 0;
-    if ( const int rc = awaitInput( c, c->inSize, &inBase, &inSize ); rc != MI355X_BZ2_OK ) return rc;
-    constexpr uint32_t CAP = 1u << 20;
-    uint64_t* dFound = nullptr;
-    uint32_t* dCounter = nullptr;
-    HIP_TRY( c, hipMalloc( &dFound, (size_t)CAP * sizeof( uint64_t ) ) );
-    if ( hipMalloc( &dCounter, sizeof( uint32_t ) ) != hipSuccess ) {
-        (void)hipFree( dFound );
-        return MI355X_BZ2_ERR_DEVICE;
+    {
+        /* the context's own lock only for the set-up: batches may be launched on it while the scan waits or runs */
+        const std::scoped_lock lock( c->mutex );
+        if ( c->dIn == nullptr && !c->upload ) {
+            c->lastError = "no input set";
+            return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+        }
+        if ( c->inSize < 6 ) return MI355X_BZ2_OK;
+        HIP_TRY( c, hipSetDevice( c->device ) );
+        if ( c->scanStream == nullptr ) HIP_TRY( c, hipStreamCreateWithFlags( &c->scanStream, hipStreamNonBlocking ) );
+        if ( c->scanOrder == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &c->scanOrder, hipEventDisableTiming ) );
+        if ( c->dScanFound == nullptr ) HIP_TRY( c, hipMalloc( &c->dScanFound, (size_t)CAP * sizeof( uint64_t ) ) );
+        if ( c->dScanCounter == nullptr ) HIP_TRY( c, hipMalloc( &c->dScanCounter, sizeof( uint32_t ) ) );
+        upload = c->upload;
+        inBase = c->dIn;
+        inSize = c->inSize;
+        if ( !upload ) {
+            /* a copy queued by set_input_host_async is on the context's stream */
+            HIP_TRY( c, hipEventRecord( c->scanOrder, c->stream ) );
+            HIP_TRY( c, hipStreamWaitEvent( c->scanStream, c->scanOrder, 0 ) );
+        }
     }
-    int rc = MI355X_BZ2_OK;
+    const auto fail = [c] ( const char* what ) {
+        const std::scoped_lock lock( c->mutex );
+        c->lastError = what;
+        return MI355X_BZ2_ERR_DEVICE;
+    };
+    if ( upload && upload->total != 0 ) {
+        /* the whole streamed copy: wait until its last piece is queued, then order the scan behind it */
+        std::unique_lock lock( upload->mutex );
+        upload->changed.wait( lock, [&] { return upload->failed || upload->queued >= upload->total; } );
+        if ( upload->failed ) {
+            lock.unlock();
+            return fail( "the streamed copy of the input failed" );
+        }
+        inBase = upload->main;
+        inSize = upload->total;
+        if ( hipStreamWaitEvent( c->scanStream, upload->done.back(), 0 ) != hipSuccess ) {
+            lock.unlock();
+            return fail( "hipStreamWaitEvent( scan ) failed" );
+        }
+    }
     uint32_t count = 0;
     std::vector<uint64_t> host;
-    do {
-        if ( hipMemsetAsync( dCounter, 0, sizeof( uint32_t ), c->stream ) != hipSuccess ) { rc = MI355X_BZ2_ERR_DEVICE; break; }
-        hipLaunchKernelGGL( k_find_magic, dim3( 4096 ), dim3( 256 ), 0, c->stream,
-                            reinterpret_cast<const uint32_t*>( inBase ), inSize * 8, magic48 & 0xFFFFFFFFFFFFULL,
-                            dFound, CAP, dCounter );
-        if ( hipMemcpyAsync( &count, dCounter, sizeof( uint32_t ), hipMemcpyDeviceToHost, c->stream ) != hipSuccess
-             || hipStreamSynchronize( c->stream ) != hipSuccess ) { rc = MI355X_BZ2_ERR_DEVICE; break; }
-        const uint32_t stored = std::min( count, CAP );
-        host.resize( stored );
-        if ( stored > 0
-             && hipMemcpy( host.data(), dFound, (size_t)stored * sizeof( uint64_t ), hipMemcpyDeviceToHost ) != hipSuccess ) {
-            rc = MI355X_BZ2_ERR_DEVICE;
-            break;
-        }
-    } while ( false );
-    (void)hipFree( dFound );
-    (void)hipFree( dCounter );
-    if ( rc != MI355X_BZ2_OK ) {
-        c->lastError = "k_find_magic failed";
-        return rc;
-    }
+    if ( hipMemsetAsync( c->dScanCounter, 0, sizeof( uint32_t ), c->scanStream ) != hipSuccess ) return fail( "k_find_magic failed" );
+    hipLaunchKernelGGL( k_find_magic, dim3( 4096 ), dim3( 256 ), 0, c->scanStream,
+                        reinterpret_cast<const uint32_t*>( inBase ), inSize * 8, magic48 & 0xFFFFFFFFFFFFULL,
+                        c->dScanFound, CAP, c->dScanCounter );
+    if ( hipMemcpyAsync( &count, c->dScanCounter, sizeof( uint32_t ), hipMemcpyDeviceToHost, c->scanStream ) != hipSuccess
+         || hipStreamSynchronize( c->scanStream ) != hipSuccess ) return fail( "k_find_magic failed" );
+    const uint32_t stored = std::min( count, CAP );
+    host.resize( stored );
+    if ( stored > 0
+         && ( hipMemcpyAsync( host.data(), c->dScanFound, (size_t)stored * sizeof( uint64_t ), hipMemcpyDeviceToHost,
+                              c->scanStream ) != hipSuccess
+              || hipStreamSynchronize( c->scanStream ) != hipSuccess ) ) return fail( "k_find_magic failed" );
     if ( count > CAP ) return MI355X_BZ2_ERR_OUTPUT_CAPACITY;
     std::sort( host.begin(), host.end() );
     *nFound = host.size();

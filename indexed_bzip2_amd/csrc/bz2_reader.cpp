@@ -29,6 +29,7 @@
 #include <iostream>
 #include <list>
 #include <memory>
+#include <optional>
 #include <queue>
 #include <sstream>
 #include <string>
@@ -165,29 +166,33 @@ public:
         for ( auto& b : m_free ) (void)hipHostFree( b.data );
     }
 
+    /** A page-locked buffer of at least `size` bytes: the smallest free one that fits, else fresh memory (which costs
+     * more than the copy it is for: 20 to 50 ms for a batch of 512 blocks).  `capacity`, if given, receives its size. */
     [[nodiscard]] std::shared_ptr<const uint8_t>
-    get( size_t size, const std::shared_ptr<PinnedPool>& self )
+    get( size_t size, const std::shared_ptr<PinnedPool>& self, size_t* capacity = nullptr )
     {
         Buffer buffer;
         {
             const std::scoped_lock lock( m_mutex );
+            auto best = m_free.end();
             for ( auto it = m_free.begin(); it != m_free.end(); ++it ) {
-                if ( it->capacity >= size ) {
-                    buffer = *it;
-                    m_free.erase( it );
-                    break;
-                }
+                if ( ( it->capacity >= size ) && ( best == m_free.end() || it->capacity < best->capacity ) ) best = it;
+            }
+            if ( best != m_free.end() ) {
+                buffer = *best;
+                m_free.erase( best );
             }
         }
         if ( buffer.data == nullptr ) {
             /* batches of one sequential read differ a little in size: leave headroom so that a recycled buffer fits
-             * the next batch instead of pinning fresh memory (which costs more than the copy) */
+             * the next batch instead of pinning fresh memory */
             const size_t grain = size < ( size_t( 8 ) << 20 ) ? ( size_t( 1 ) << 20 ) : ( size_t( 16 ) << 20 );
             buffer.capacity = ( std::max<size_t>( size + size / 8, 1 ) + grain - 1 ) / grain * grain;
             if ( hipHostMalloc( reinterpret_cast<void**>( &buffer.data ), buffer.capacity, hipHostMallocDefault ) != hipSuccess ) {
                 return nullptr;
             }
         }
+        if ( capacity != nullptr ) *capacity = buffer.capacity;
         /* the deleter hands the memory back; the pool lives as long as any buffer does */
         return std::shared_ptr<const uint8_t>( buffer.data, [self, buffer] ( const uint8_t* ) { self->put( buffer ); } );
     }
@@ -197,7 +202,7 @@ private:
     put( Buffer buffer )
     {
         const std::scoped_lock lock( m_mutex );
-        if ( m_free.size() < 4 ) {
+        if ( m_free.size() < 8 ) {
             m_free.push_back( buffer );
             return;
         }
@@ -256,13 +261,15 @@ public:
         m_finder( std::move( finder ) ),
         m_batch( std::max<size_t>( 1, parallelization ) ),
         m_contexts( contextCount( m_batch ) ),
-        /* blocks that may be decoded ahead of the reader, finished or in flight: every context a full batch in flight
-         * while another one is being read */
-        m_window( ( m_contexts + 2 ) * m_batch ),
+        /* blocks that may be decoded ahead of the reader, finished or in flight: every context a full batch in flight and
+         * one more queued (a context that has finished finds its next launch without waiting for the reading thread),
+         * while another two are finished and being read */
+        m_window( ( m_contexts + 3 ) * m_batch ),
         m_ready( m_window + std::max<size_t>( 16, m_batch ) )
     {
         /* BZ2BlockFetcher's constructor reads the stream header once: BZ2BlockFetcher.hpp:56 */
-        if ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), 0 ) == 0 ) {
+        m_level = mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), 0 );
+        if ( m_level == 0 ) {
             fail( MI355X_BZ2_ERR_STREAM_HEADER );
         }
         /* Several decoder contexts, each with its own submission thread: while one batch is copied to the host (and
@@ -280,7 +287,7 @@ public:
             std::fprintf( stderr, "[reader] first context, copy of %.0f MB started: %.1f ms\n", m_source->size() / 1e6,
                           std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tCreate ).count() );
         }
-        scanOnDevice();
+        m_scanner = std::thread( [this] { scanOnDevice(); } );
         for ( size_t i = 0; i < m_contexts; ++i ) {
             m_workers.emplace_back( [this, i, device] () {
                 if ( i > 0 ) {
@@ -329,6 +336,7 @@ public:
             m_stop = true;
             m_queueChanged.notify_all();
         }
+        if ( m_scanner.joinable() ) m_scanner.join();
         for ( auto& worker : m_workers ) {
             if ( worker.joinable() ) worker.join();
         }
@@ -396,7 +404,6 @@ public:
     demand( size_t block )
     {
         ++m_stats.gets;
-        scanOnDevice();
         collectFinished();
         m_pattern.note( block );
         if ( m_pattern.inOrder() ) {
@@ -404,6 +411,7 @@ public:
         }
 
         std::shared_future<RunPtr> pending;
+        bool onDemand = false;
         RunPtr run = m_ready.find( block );
         if ( run ) {
             ++( run->lookAhead ? m_stats.prefetch_hits : m_stats.cache_hits );
@@ -415,8 +423,10 @@ public:
              * everything queued, and what should follow it as a second launch on another context. */
             ++m_stats.on_demand_fetches;
             pending = launch( block, 1, /* urgent */ true, /* lookAhead */ false );
+            onDemand = true;
         }
-        launchAhead( block, /* somebodyWaits */ pending.valid() );
+        /* (a reader that waits for a launch in flight gains nothing from a partial launch behind it) */
+        launchAhead( block, /* somebodyWaits */ onDemand );
 
         if ( !run ) {
             const auto tWait = std::chrono::steady_clock::now();
@@ -470,26 +480,31 @@ private:
         return block - behind->first < behind->second.count ? behind : m_flights.end();
     }
 
-    /** Once the whole file is resident on the GPU: let it find the block magics too (k_find_magic, a few ms per GB); the
-     * host finder threads (about 1.3 GB/s of compressed data on eight cores), which serve the first blocks while the
-     * copy runs, would pace the whole reader.  Same offsets, delivered at once; if the scan cannot be used (more matches
-     * than its result buffer holds) the host threads carry on. */
+    /** A thread of its own: once the whole file is resident on the GPU, let it find the block magics too (k_find_magic,
+     * a few ms per GB, on a stream of its own); the host finder threads (about 1.3 GB/s of compressed data on eight
+     * cores), which serve the first blocks while the copy runs, would pace the whole reader.  Same offsets, delivered at
+     * once; if the scan cannot be used (more matches than its result buffer holds) the host threads carry on. */
     void
     scanOnDevice()
     {
-        if ( m_scanned || m_finder->finalized() ) {
-            m_scanned = true;
-            return;
+        const auto stopped = [this] {
+            const std::scoped_lock lock( m_queueMutex );
+            return m_stop;
+        };
+        while ( mi355x_bz2_input_resident( m_ctxs.front() ) == 0 ) {
+            if ( stopped() || m_finder->finalized() ) return;
+            std::this_thread::sleep_for( std::chrono::milliseconds( 2 ) );
         }
-        if ( mi355x_bz2_input_resident( m_ctxs.front() ) == 0 ) return;
-        m_scanned = true;
+        if ( stopped() || m_finder->finalized() ) return;
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
         uint64_t found = 0;
         if ( ( mi355x_bz2_find_magic_device( m_ctxs.front(), MI355X_BZ2_MAGIC_BLOCK, offsets.data(), offsets.size(),
                                              &found ) == MI355X_BZ2_OK ) && ( found <= offsets.size() ) ) {
             offsets.resize( found );
-            m_finder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
+            if ( !m_finder->finalized() ) {   /* an index given by the caller meanwhile stays */
+                m_finder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
+            }
         }
         if ( m_trace ) {
             const auto now = std::chrono::steady_clock::now();
@@ -529,7 +544,9 @@ private:
     void
     launchAhead( size_t block, bool somebodyWaits )
     {
-        const size_t limit = m_batch * m_contexts;           /* one full batch per context in flight */
+        /* one full batch per context in flight, and one queued: launches are made on the reading thread, which may be
+         * blocked on a run when a context becomes free */
+        const size_t limit = m_batch * ( m_contexts + ( m_batch >= 64 ? 1 : 0 ) );
         if ( m_inFlightBlocks >= limit ) return;
         /* While a launch is held back for want of blocks (rule at the end) a sequential reader gains about one candidate
          * per call: looking again on every call would cost O(batch^2) per batch. */
@@ -571,10 +588,12 @@ private:
             m_holdOff = std::max<size_t>( 1, m_batch / 8 );
             return;
         }
-        /* A launch has a latency floor: go along with a launch somebody waits for, otherwise wait until half a batch
-         * can go at once -- unless nothing is in flight at all. */
-        const size_t worthIt = std::max<size_t>( 1, m_batch / 2 );
-        if ( somebodyWaits || ( offsets.size() >= std::min( worthIt, m_ramp ) ) || m_flights.empty() ) {
+        /* A launch has a latency floor (its slowest block, 30 to 45 ms) whatever its size: go along with a launch somebody
+         * waits for, otherwise wait until a whole batch can go (the ramp's size while the reader starts up) -- unless nothing is
+         * in flight at all or the file ends here. */
+        const size_t worthIt = m_batch;
+        const bool reachesEnd = m_finder->finalized() && ( from + offsets.size() >= m_finder->size() );
+        if ( somebodyWaits || ( offsets.size() >= std::min( worthIt, m_ramp ) ) || m_flights.empty() || reachesEnd ) {
             m_ramp = std::min( m_batch, 4 * m_ramp );
             m_stats.prefetches_submitted += offsets.size();
             launch( from, std::move( offsets ), /* urgent */ false, /* lookAhead */ true );
@@ -626,64 +645,45 @@ private:
     }
 
     /** One submission thread per decoder context: takes a launch, decodes the batch, copies it to a page-locked buffer,
-     * publishes the run.  Replaces the thread pool of per-block tasks (BlockFetcher.hpp:620-642). */
+     * publishes the run.  Replaces the thread pool of per-block tasks (BlockFetcher.hpp:620-642).
+     * The copy of a batch runs in the background while the context's next batch is launched (the context writes to a
+     * second output buffer meanwhile), and the page-locked buffer is fetched while the GPU is decoding. */
     void
     workerMain( mi355x_bz2_ctx* const ctx )
     {
-        while ( true ) {
+        struct Step
+        {
             std::unique_ptr<Launch> work;
-            {
-                std::unique_lock lock( m_queueMutex );
-                m_queueChanged.wait( lock, [this] { return m_stop || !m_queue.empty(); } );
-                if ( m_queue.empty() ) {
-                    return;   /* m_stop */
-                }
-                work = std::move( m_queue.front() );
-                m_queue.pop_front();
-            }
-            const auto t0 = std::chrono::steady_clock::now();
-            const auto n = (uint32_t)work->offsets.size();
-            std::vector<mi355x_bz2_block_result> results( n );
-            uint64_t total = 0;
-            int rc = mi355x_bz2_decode_batch( ctx, work->offsets.data(), n, results.data(), &total );
-            const auto t1 = std::chrono::steady_clock::now();
-            auto t2 = t1;
+            std::vector<mi355x_bz2_block_result> results;
             std::shared_ptr<const uint8_t> buffer;
-            if ( rc == MI355X_BZ2_OK ) {
-                buffer = m_hostBuffers->get( total, m_hostBuffers );
-                t2 = std::chrono::steady_clock::now();
-                if ( !buffer ) {
-                    rc = MI355X_BZ2_ERR_DEVICE;
-                } else if ( total > 0 ) {
-                    rc = mi355x_bz2_copy_output( ctx, 0, total, const_cast<uint8_t*>( buffer.get() ) );
-                }
+            uint64_t total{ 0 };
+            std::chrono::steady_clock::time_point t0;
+        };
+        const auto failStep = [this, ctx] ( Step& step ) {
+            {
+                const std::scoped_lock lock( m_queueMutex );
+                m_workerError = mi355x_bz2_last_error( ctx );
             }
-            if ( m_trace ) {
-                const auto ms = [] ( auto a, auto b ) { return std::chrono::duration<double, std::milli>( b - a ).count(); };
-                const auto t3 = std::chrono::steady_clock::now();
-                std::fprintf( stderr, "[reader] t=%.1f ms: blocks [%zu, +%u) on ctx %p: decode %.1f ms, host buffer %.1f ms, "
-                              "copy of %.0f MB %.1f ms\n", ms( m_created, t0 ), work->first, n, (void*)ctx, ms( t0, t1 ),
-                              ms( t1, t2 ), total / 1e6, ms( t2, t3 ) );
+            step.work->promise.set_value( nullptr );
+            step.work->done->store( true, std::memory_order_release );
+        };
+        /* the copy of `step` has been queued: wait for it and hand the run over */
+        const auto publish = [this, ctx, &failStep] ( Step& step ) {
+            if ( mi355x_bz2_copy_output_end( ctx ) != MI355X_BZ2_OK ) {
+                failStep( step );
+                return;
             }
-            if ( rc != MI355X_BZ2_OK ) {
-                {
-                    const std::scoped_lock lock( m_queueMutex );
-                    m_workerError = mi355x_bz2_last_error( ctx );
-                }
-                work->promise.set_value( nullptr );
-                work->done->store( true, std::memory_order_release );
-                continue;
-            }
+            const auto n = step.results.size();
             auto run = std::make_shared<DecodedRun>();
-            run->firstBlock = work->first;
-            run->bytes = std::move( buffer );
-            run->totalBytes = total;
-            run->lookAhead = work->lookAhead;
+            run->firstBlock = step.work->first;
+            run->bytes = std::move( step.buffer );
+            run->totalBytes = step.total;
+            run->lookAhead = step.work->lookAhead;
             run->blocks.resize( n );
-            for ( uint32_t i = 0; i < n; ++i ) {
-                const auto& r = results[i];
+            for ( size_t i = 0; i < n; ++i ) {
+                const auto& r = step.results[i];
                 auto& record = run->blocks[i];
-                record.bits = work->offsets[i];
+                record.bits = step.work->offsets[i];
                 record.bitLength = r.encoded_size_bits;
                 record.storedCrc = r.header_crc;
                 record.computedCrc = r.computed_crc;
@@ -695,13 +695,75 @@ private:
                     record.byteLength = r.decoded_size;
                 }
             }
-            work->promise.set_value( std::move( run ) );
-            work->done->store( true, std::memory_order_release );
+            step.work->promise.set_value( std::move( run ) );
+            step.work->done->store( true, std::memory_order_release );
             const std::scoped_lock lock( m_queueMutex );
             ++m_batches;
             m_blocksDecoded += n;
-            m_decodeSeconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+            m_decodeSeconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - step.t0 ).count();
+        };
+
+        std::optional<Step> copying;    /* decoded, on its way to the host */
+        while ( true ) {
+            Step step;
+            {
+                std::unique_lock lock( m_queueMutex );
+                if ( copying && m_queue.empty() && !m_stop ) {
+                    /* nothing to launch beside the copy: finish it first, somebody may be waiting for exactly this run */
+                    lock.unlock();
+                    publish( *copying );
+                    copying.reset();
+                    lock.lock();
+                }
+                m_queueChanged.wait( lock, [this] { return m_stop || !m_queue.empty(); } );
+                if ( m_queue.empty() ) {
+                    break;   /* m_stop */
+                }
+                step.work = std::move( m_queue.front() );
+                m_queue.pop_front();
+            }
+            step.t0 = std::chrono::steady_clock::now();
+            const auto n = (uint32_t)step.work->offsets.size();
+            step.results.resize( n );
+            int rc = mi355x_bz2_decode_batch_begin( ctx, step.work->offsets.data(), n );
+            const auto t1 = std::chrono::steady_clock::now();
+            /* while the GPU works: the run in front of this one, and the memory for this one (a block of the usual
+             * compressors decodes to at most level x 100 000 bytes; if these decode to more -- later streams of the file
+             * may have a higher level -- a second buffer is fetched below) */
+            if ( copying ) {
+                publish( *copying );
+                copying.reset();
+            }
+            size_t capacity = 0;
+            if ( rc == MI355X_BZ2_OK ) {
+                step.buffer = m_hostBuffers->get( (size_t)n * m_level * 100000 + 4096, m_hostBuffers, &capacity );
+            }
+            const auto t2 = std::chrono::steady_clock::now();
+            if ( rc == MI355X_BZ2_OK ) {
+                rc = mi355x_bz2_decode_batch_end( ctx, step.results.data(), &step.total );
+            }
+            const auto t3 = std::chrono::steady_clock::now();
+            if ( rc == MI355X_BZ2_OK ) {
+                if ( step.total > capacity ) step.buffer = m_hostBuffers->get( step.total, m_hostBuffers );
+                if ( !step.buffer ) {
+                    rc = MI355X_BZ2_ERR_DEVICE;
+                } else {
+                    rc = mi355x_bz2_copy_output_begin( ctx, 0, step.total, const_cast<uint8_t*>( step.buffer.get() ) );
+                }
+            }
+            if ( m_trace ) {
+                const auto ms = [] ( auto a, auto b ) { return std::chrono::duration<double, std::milli>( b - a ).count(); };
+                std::fprintf( stderr, "[reader] t=%.1f ms: blocks [%zu, +%u) on ctx %p: launch %.1f ms, previous run + host "
+                              "buffer %.1f ms, rest of the decode %.1f ms, %.0f MB\n", ms( m_created, step.t0 ),
+                              step.work->first, n, (void*)ctx, ms( step.t0, t1 ), ms( t1, t2 ), ms( t2, t3 ), step.total / 1e6 );
+            }
+            if ( rc != MI355X_BZ2_OK ) {
+                failStep( step );
+                continue;
+            }
+            copying = std::move( step );
         }
+        if ( copying ) publish( *copying );
     }
 
 private:
@@ -717,11 +779,12 @@ private:
     size_t m_inFlightBlocks{ 0 };
     size_t m_holdOff{ 0 };
     size_t m_ramp{ 64 };         /* blocks of the next look-ahead launch while the reader is starting up */
-    bool m_scanned{ false };     /* the GPU has delivered the block offsets (or will not) */
+    unsigned m_level{ 9 };       /* of the first stream: 100 000 bytes per block and level */
 
     std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };
     std::vector<std::thread> m_workers;
+    std::thread m_scanner;       /* see scanOnDevice */
     mutable std::mutex m_queueMutex;
     std::condition_variable m_queueChanged;
     std::deque<std::unique_ptr<Launch> > m_queue;

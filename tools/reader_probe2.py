@@ -18,13 +18,19 @@ def main():
     with open(big, "wb") as f:
         for _ in range(copies):
             f.write(enc)
+    if os.environ.get("PROBE_WARMUP") == "1":      # what an application that calls ibz2.warmup() while it starts sees
+        t = time.perf_counter()
+        m.warmup(background=False)
+        print(f"warmup {1e3 * (time.perf_counter() - t):.0f} ms", flush=True)
     for P in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1280,2560")]:
         fd = os.open("/dev/null", os.O_WRONLY)
         t0 = time.perf_counter()
         f = m.IndexedBzip2FileRaw(big, P)
         f.bz2reader.set_verify_stream_crc(True)
         t1 = time.perf_counter()
-        n = f.bz2reader.read_to_fd(fd, 1 << 20)
+        n = f.bz2reader.read_to_fd(fd, 1)
+        tb = time.perf_counter()
+        n += f.bz2reader.read_to_fd(fd, (1 << 20) - 1)
         t2 = time.perf_counter()
         marks = []
         while True:
@@ -39,7 +45,7 @@ def main():
         f.close()
         os.close(fd)
         per_gib = [round((b - a) * 1e3) for a, b in zip([t2] + marks[:-1], marks)]
-        print(f"P={P}: {n / dt / 1e6:.0f} MB/s total ({dt:.2f} s); open {1e3 * (t1 - t0):.0f} ms, first MiB {1e3 * (t2 - t1):.0f} ms, "
+        print(f"P={P}: {n / dt / 1e6:.0f} MB/s total ({dt:.2f} s); open {1e3 * (t1 - t0):.0f} ms, first byte {1e3 * (tb - t0):.0f} ms, first MiB {1e3 * (t2 - t0):.0f} ms, "
               f"ms per GiB {per_gib}; batches={st['batches']} decode_s={st['decode_seconds']:.2f} wait_s={st['wait_seconds']:.2f}",
               flush=True)
 
