@@ -958,6 +958,9 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * (DESIGN.md section 4): both are bound by instruction issue, and the pair does ~25 % more of it */
     const char* spc = std::getenv( "MI355X_BZ2_SCAN_PC" );
     const bool scanPc = spc != nullptr && spc[0] == '1';
+    /* 0: the waves of a block share the rows of one build (k_hscan<4 / 8>) instead of taking one group each (k_hscan_spec) */
+    const char* ssp = std::getenv( "MI355X_BZ2_SCAN_SPEC" );
+    const bool scanSpec = !( ssp != nullptr && ssp[0] == '0' );
     const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
     const uint32_t scanTune = st != nullptr ? (uint32_t)std::atoi( st ) : 0u;
     const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
@@ -995,7 +998,13 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
              * the next groups, see bz2_hscan.hip.h) when few blocks have to be through quickly */
             const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves : ( n <= 64 ? 8u : ( n <= 1280 ? 4u : 1u ) );
             const auto* const inWords = reinterpret_cast<const uint32_t*>( inBase );
-            if ( scanWaves >= 8 ) {
+            if ( scanWaves >= 8 && scanSpec ) {
+                TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            } else if ( scanWaves >= 4 && scanSpec ) {
+                TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<4>, dim3( m ), dim3( 256 ), 0, q, inWords, inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+            } else if ( scanWaves >= 8 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             } else if ( scanWaves >= 4 ) {

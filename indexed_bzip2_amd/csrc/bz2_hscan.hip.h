@@ -115,11 +115,13 @@ struct ScanShared
     };
 };
 
-/** Stream word `index` (relative to the block's base word) = `value` into the ring: high half of entry `index`, low half
- * of entry `index - 1`, and their mirrors. */
+/** Stream word `index` (relative to the block's base word), as loaded (little-endian view of the big-endian stream), into
+ * the ring: high half of entry `index`, low half of entry `index - 1`, and their mirrors.  The byte swap is done here and
+ * not where the word was loaded: the load is issued one refill ahead, and a swap behind it would wait for the memory. */
 __device__ __forceinline__ void
-ring_put( uint32_t* ring, uint32_t index, uint32_t value )
+ring_put( uint32_t* ring, uint32_t index, uint32_t raw )
 {
+    const uint32_t value = be32( raw );
     const uint32_t e1 = index & ( SCAN_RING_ENTRIES - 1 );
     const uint32_t e0 = ( index - 1 ) & ( SCAN_RING_ENTRIES - 1 );
     ring[2 * e1 + 1] = value;
@@ -146,12 +148,15 @@ scan_sync()
  * Codes longer than the index bits of the length table are rare per position but present in most rows: their positions
  * are collected (arrays b and c are free until the first doubling) and resolved in ONE pass of range comparisons
  * instead of one per row. */
-constexpr int SCAN_ALL = 0, SCAN_J1_ONLY = 1, SCAN_LEVELS_ONLY = 2;   /* parts of scan_build, see k_hscan_pc */
+/* parts of scan_build: J1 / rounds only (k_hscan_pc); SCAN_ENDS: J1, the rounds up to J16 and then, for the first 64 x
+ * endRows positions, where the 50-symbol group that starts there ends (k_hscan_spec) */
+constexpr int SCAN_ALL = 0, SCAN_J1_ONLY = 1, SCAN_LEVELS_ONLY = 2, SCAN_ENDS = 3;
 
 template<uint32_t K, uint32_t RW, bool NEAR_END, int PART = SCAN_ALL>
 __device__ __forceinline__ void
 scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p, uint32_t sizeBits,
-            const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane, uint32_t wave )
+            const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane, uint32_t wave,
+            uint32_t endRows = 0, uint32_t endBase = 0 )
 {
     constexpr uint32_t S = 64 * K * RW;
     constexpr uint32_t OUT = 2 * S, TERM = 2 * S + 2;
@@ -234,7 +239,7 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
     }
     }
     if constexpr ( PART == SCAN_J1_ONLY ) return;
-    if constexpr ( PART == SCAN_ALL ) scan_sync<K>();
+    if constexpr ( PART == SCAN_ALL || PART == SCAN_ENDS ) scan_sync<K>();
     /* one round of doubling: own[j] = src[own[j]], the same into dst */
 #define SCAN_LEVEL( src, toDst ) \
     _Pragma( "unroll" ) for ( uint32_t j = 0; j < RW; ++j ) own[j] = *reinterpret_cast<const uint16_t*>( src + own[j] ); \
@@ -244,6 +249,22 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
     SCAN_LEVEL( B, TO_C )   /* J4 */
     SCAN_LEVEL( C, 0 )      /* J8 */
     SCAN_LEVEL( A, TO_C )   /* J16 -> c (kept) */
+    if constexpr ( PART == SCAN_ENDS ) {
+        /* 16 + 16 + 16 + 2 symbols from each of the first positions (own[] = J16 of them) -> a (J8 is not needed any more),
+         * as bit positions from endBase bits in front of the span: what the chain of k_hscan_spec reads */
+#pragma unroll
+        for ( uint32_t j = 0; j < RW; ++j ) {
+            if ( j < endRows ) {
+                uint32_t e = *reinterpret_cast<const uint16_t*>( C + own[j] );
+                e = *reinterpret_cast<const uint16_t*>( C + e );
+                e = *reinterpret_cast<const uint16_t*>( B + e );
+                e = e == OUT ? 0xFFFFu : ( e == TERM ? 0xFFFEu : endBase + ( e >> 1 ) );
+                *reinterpret_cast<uint16_t*>( mine + STEP * j ) = (uint16_t)e;
+            }
+        }
+        scan_sync<K>();
+        return;
+    }
     if ( firstOnly ) {
         if constexpr ( PART != SCAN_LEVELS_ONLY ) {   /* (the consumer of k_hscan_pc reads J16 twice instead) */
             if ( wave == 0 ) {
@@ -534,24 +555,24 @@ scan_rows_per_wave( uint32_t rows )
     return rw <= 8 ? ( 8u < MAX ? 8u : MAX ) : ( rw <= 10 ? ( 10u < MAX ? 10u : MAX ) : ( rw <= 12 ? ( 12u < MAX ? 12u : MAX ) : MAX ) );
 }
 
-template<uint32_t K>
+template<uint32_t K, int PART = SCAN_ALL>
 __device__ __forceinline__ void
 scan_build_rows( uint32_t rw, bool nearEnd, ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p,
                  uint32_t sizeBits, const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool one, uint32_t lane,
-                 uint32_t wave )
+                 uint32_t wave, uint32_t endRows = 0, uint32_t endBase = 0 )
 {
     constexpr uint32_t MAX = SCAN_ROWS / K;
 #define SCAN_CASE( n ) \
     if constexpr ( ( n ) <= MAX ) { \
-        if ( rw == ( n ) ) { scan_build<K, ( n ), false>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave ); return; } \
+        if ( rw == ( n ) ) { scan_build<K, ( n ), false, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase ); return; } \
     }
     if ( nearEnd ) {
-        scan_build<K, MAX, true>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave );
+        scan_build<K, MAX, true, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
         return;
     }
     SCAN_CASE( 1 ) SCAN_CASE( 2 ) SCAN_CASE( 3 ) SCAN_CASE( 4 ) SCAN_CASE( 5 ) SCAN_CASE( 6 ) SCAN_CASE( 8 ) SCAN_CASE( 10 )
     SCAN_CASE( 12 )
-    scan_build<K, MAX, false>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave );
+    scan_build<K, MAX, false, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
 #undef SCAN_CASE
 }
 
@@ -604,7 +625,7 @@ k_hscan( const uint32_t* __restrict__ in_words,
         /* stream ring: words [wHi - 256, wHi) are in sh.ring, the next 64 are on their way in `pend` (wave 0 fills) */
         uint32_t wHi = 0;
         uint32_t pend = 0;
-        if ( wave == 0 ) pend = lane < nWords ? be32( words[lane] ) : 0u;
+        if ( wave == 0 && lane < nWords ) pend = words[lane];
         /* selectors of groups [64 k, 64 k + 64), one per lane, the next 64 on their way */
         uint32_t selV = sel[lane];
         uint32_t selPend = sel[64 + lane];
@@ -625,7 +646,8 @@ k_hscan( const uint32_t* __restrict__ in_words,
                 while ( ( p >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
                     if ( wave == 0 ) {
                         ring_put( sh.ring, wHi + lane, pend );
-                        pend = wHi + 64 + lane < nWords ? be32( words[wHi + 64 + lane] ) : 0u;
+                        pend = 0;
+                        if ( wHi + 64 + lane < nWords ) pend = words[wHi + 64 + lane];
                     }
                     wHi += 64;
                 }
@@ -762,6 +784,304 @@ k_hscan( const uint32_t* __restrict__ in_words,
 }
 
 /* =============================================================================================================
+ * k_hscan_spec: the scan with K waves per block that work on K CONSECUTIVE GROUPS at once.
+ *
+ * The chain from group to group is what makes a block slow when few blocks are decoded (one reader, one rank's share of a
+ * file): a group's start is known only when the group in front of it has been measured.  But it is known APPROXIMATELY:
+ * the groups of a table are about as long as its last ones (text: +- 12 %; incompressible data: 399 +- 1 bits).  So wave
+ * w takes group g + w, lays a window over every position where that group can start -- the sum of the expected
+ * lengths of the groups in front of it, minus and plus their observed deviations -- and computes, for EVERY start in
+ * the window, where the group ends (J1 and the doubling rounds over the window plus one group, as in k_hscan, by the wave
+ * alone and without barriers; then 16 + 16 + 16 + 2 symbols from each candidate start).  After one barrier the K groups
+ * are chained with one LDS read each: the end of group w - 1 is the start of group w, if it lies in w's window.  If not
+ * (a stray group, a table seen for the first time, the end of the input near), the unit ends there and the next one
+ * starts at the true position: a guess decides how many groups a unit completes, never where a group starts.
+ * Group g itself starts at a known position, so every unit completes at least one group.
+ * ============================================================================================================= */
+template<uint32_t K>
+struct SpecShared
+{
+    ScanShared<1> s;          /* tables, ring, header; its slot is wave 0's */
+    ScanSlot more[K - 1];     /* the slots of waves 1 .. K - 1 */
+
+    __device__ __forceinline__ ScanSlot& slot( uint32_t w ) { return w == 0 ? s.slot[0] : more[w - 1]; }
+};
+
+constexpr uint32_t SPEC_REACH = 3400;   /* bits in front of the current position that a unit may look (the stream ring holds
+                                           8 192, of which a build needs 1 120 behind its start) */
+
+template<uint32_t K>
+__global__ __launch_bounds__( 64 * K ) void
+k_hscan_spec( const uint32_t* __restrict__ in_words,
+              uint64_t                     in_size_bytes,
+              const uint64_t* __restrict__ offsets,
+              BlockMeta* __restrict__      meta,
+              HuffMeta* __restrict__       hmeta,
+              ScanMeta* __restrict__       smeta,
+              uint8_t*                     sel_buf,
+              uint8_t* __restrict__        stb_buf,
+              HuffTables* __restrict__     tab_buf,
+              uint32_t* __restrict__       gpos_buf,
+              uint32_t                     n_blocks,
+              const uint32_t* __restrict__ order,
+              uint32_t                     tune )   /* debugging: 1 = one group per unit */
+{
+    __shared__ SpecShared<K> shared;
+    ScanShared<1>& sh = shared.s;
+    const uint32_t slotIndex = blockIdx.x;
+    if ( slotIndex >= n_blocks ) return;
+    const uint32_t b = sfl( order[slotIndex] );
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = sfl( threadIdx.x >> 6 );
+    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
+    uint32_t* const gpos = gpos_buf + (size_t)b * GPOS_STRIDE;
+    const uint64_t start = offsets[b];
+
+    if ( wave == 0 ) {
+        scan_parse<1>( sh, in_words, in_size_bytes, start, sel, stb_buf, tab_buf + b, b, lane );
+        __threadfence_block();   /* the selectors are read back below */
+    }
+    __syncthreads();
+
+    const uint32_t active = sfl( sh.hdr.active );
+    int32_t status = (int32_t)sfl( (uint32_t)sh.hdr.status );
+    const uint32_t nSel = sfl( sh.hdr.n_sel );
+    const uint32_t sizeBits = sfl( sh.hdr.size_bits );
+    const uint32_t nWords = sfl( sh.hdr.n_words );
+    const uint64_t posBase = ( (uint64_t)sfl( (uint32_t)( sh.hdr.pos_base >> 32 ) ) << 32 ) | sfl( (uint32_t)sh.hdr.pos_base );
+    uint32_t nGroups = 0, terminal = 0;
+
+    if ( active ) {
+        const uint32_t* const words = in_words + ( posBase >> 5 );
+        ScanSlot& mySlot = shared.slot( wave );
+        uint32_t p = sfl( sh.hdr.p0 );
+        uint32_t g = 0;
+        /* stream ring: words [wHi - 256, wHi) are in sh.ring.  A unit takes up to 3 400 bits, more than one refill of 64
+         * words: the waves take turns, wave w holds the words of the next piece q (64 words) with q mod K == w, loaded K
+         * refills ahead */
+        uint32_t wHi = 0, pend = 0;
+        if ( 64 * wave + lane < nWords ) pend = words[64 * wave + lane];
+        /* selectors of groups [64 k, 64 k + 64), one per lane, and of the next 64 */
+        uint32_t selV = sel[lane];
+        uint32_t selNext = sel[64 + lane];
+        /* per table (lane t = table t): the largest recent group length (0: table not seen yet), a running mean of the
+         * lengths and the largest recent deviation from it */
+        uint32_t estV = 0, midV = 0, devV = 0;
+        uint32_t gposV = 0;
+        uint32_t lastS = 0, lastT = 0xFFFFFFFFu;     /* of this wave's slot / of this wave's code ranges */
+        uint32_t lim[10] = {};
+        uint32_t eobLo = 0, eobHi = 0;
+        bool forceFull = false;
+
+        for ( ;; ) {
+            if ( g >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
+            if ( g >= MAX_SCAN_GROUPS ) { status = ST_DATA_OVERFLOW; break; }
+            /* ---- the plan of the unit, the same in every wave: group g + w in slot w for w < n; lane w plans slot w ---- */
+            uint32_t tV, loV, widthV, rowsV;     /* lane w: table, start of the window relative to p, its width, rows of the build */
+            uint32_t n;
+            {
+                const uint32_t gw = g + lane;
+                const uint32_t fromNext = ( gw >> 6 ) != ( g >> 6 ) ? 1u : 0u;
+                const uint32_t tHere = (uint32_t)__shfl( (int)selV, (int)( gw & 63u ) );
+                const uint32_t tNext = (uint32_t)__shfl( (int)selNext, (int)( gw & 63u ) );
+                tV = ( fromNext ? tNext : tHere ) & 7u;
+                const uint32_t est = (uint32_t)__shfl( (int)estV, (int)tV );
+                const uint32_t mid = (uint32_t)__shfl( (int)midV, (int)tV );
+                const uint32_t dev = (uint32_t)__shfl( (int)devV, (int)tV );
+                const uint32_t need = est + ( est >> 3 ) + 16;       /* a group of this table: largest recent + 12 % + 16 bits */
+                const uint32_t slack = dev + ( dev >> 2 ) + 2;
+                const uint32_t stepLo = mid > slack + 50 ? mid - slack : 50u;      /* 50 symbols are at least 50 bits */
+                const uint32_t stepHi = mid + slack;
+                /* exclusive prefix sums over the first lanes (K <= 8: inside one row of 16 lanes) */
+                uint32_t accLo = stepLo, accHi = stepHi;
+#define SPEC_SCAN_STEP( k ) \
+                if constexpr ( ( k ) < K ) { \
+                    accLo += (uint32_t)__builtin_amdgcn_update_dpp( 0, (int)accLo, 0x110 + ( k ), 0xF, 0xF, true );   /* row_shr:k, 0 shifted in */ \
+                    accHi += (uint32_t)__builtin_amdgcn_update_dpp( 0, (int)accHi, 0x110 + ( k ), 0xF, 0xF, true ); \
+                }
+                SPEC_SCAN_STEP( 1 ) SPEC_SCAN_STEP( 2 ) SPEC_SCAN_STEP( 4 )
+#undef SPEC_SCAN_STEP
+                accLo -= stepLo;
+                accHi -= stepHi;
+                loV = accLo;
+                widthV = accHi - accLo;
+                rowsV = scan_rows_per_wave<1>( ( widthV + need + 24 + 63 ) >> 6 );
+                const bool ok = ( lane < K ) && ( gw < nSel ) && ( gw < MAX_SCAN_GROUPS ) && !( ( tune & 1u ) && lane > 0 )
+                                && ( est != 0 ) && ( widthV + need + 24 <= SCAN_MAX_SPAN ) && ( accHi <= SPEC_REACH )
+                                && ( p + accLo + SCAN_MAX_SPAN + 32 <= sizeBits );
+                const uint64_t okMask = __ballot( ok );
+                n = (uint32_t)__builtin_ctzll( ~okMask );            /* slots 0 .. n - 1 are usable */
+                if ( forceFull ) n = 0;
+            }
+            const bool full = n == 0;     /* first group of a table, near the end of the input, or a group that left its span */
+            const bool nearEnd = p + SCAN_MAX_SPAN + 32 > sizeBits;
+            if ( full ) {
+                n = 1;
+                tV = (uint32_t)__builtin_amdgcn_readlane( (int)selV, g & 63u );
+                loV = 0; widthV = 0; rowsV = SCAN_ROWS;
+            }
+            /* ---- stream words up to the end of the farthest build (every wave keeps count, wave 0 moves the words) ---- */
+            {
+                const uint32_t far = (uint32_t)__builtin_amdgcn_readlane( (int)loV, n - 1 );
+                const uint32_t needWord = ( ( p + far ) >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32;
+                if ( needWord > wHi ) {
+                    while ( needWord > wHi ) {
+                        if ( ( ( wHi >> 6 ) & ( K - 1 ) ) == wave ) {
+                            ring_put( sh.ring, wHi + lane, pend );
+                            pend = 0;
+                            if ( wHi + 64 * K + lane < nWords ) pend = words[wHi + 64 * K + lane];
+                        }
+                        wHi += 64;
+                    }
+                    __syncthreads();
+                }
+            }
+            /* ---- every wave builds its slot ---- */
+            if ( wave < n ) {
+                const uint32_t myT = (uint32_t)__builtin_amdgcn_readlane( (int)tV, wave );
+                const uint32_t myLo = (uint32_t)__builtin_amdgcn_readlane( (int)loV, wave );
+                const uint32_t myWidth = (uint32_t)__builtin_amdgcn_readlane( (int)widthV, wave );
+                const uint32_t myRows = (uint32_t)__builtin_amdgcn_readlane( (int)rowsV, wave );
+                if ( myT != lastT ) {
+                    const uint32_t mx = sfl( sh.minmax[myT] ) >> 8;
+                    const uint32_t limV = sh.limit[myT][lane < mx ? lane : mx];
+#pragma unroll
+                    for ( uint32_t l = 0; l < 10; ++l ) lim[l] = (uint32_t)__builtin_amdgcn_readlane( (int)limV, 11 + l );
+                    eobLo = sfl( sh.eob_lo[myT] );
+                    eobHi = sfl( sh.eob_hi[myT] );
+                    lastT = myT;
+                }
+                const uint32_t S = 64 * myRows;
+                if ( S != lastS ) {
+                    if ( lane < 2 ) {
+                        const uint16_t v = (uint16_t)( 2 * ( S + lane ) );
+                        mySlot.at( 0, S + lane ) = v; mySlot.at( 1, S + lane ) = v; mySlot.at( 2, S + lane ) = v;
+                    }
+                    lastS = S;
+                }
+                scan_build_rows<1, SCAN_ENDS>( myRows, full && nearEnd, mySlot, sh.lenlut[myT], sh.ring, p + myLo, sizeBits, lim,
+                                               eobLo, eobHi, false, lane, 0, ( myWidth >> 6 ) + 1, myLo );
+            }
+            __syncthreads();
+            /* ---- chain the groups: every wave follows the same chain (uniform LDS reads).  A slot's candidates hold the end
+             * of their group relative to p (0xFFFF: beyond the span, 0xFFFE: the group stops the block); lane w keeps the
+             * end of group w ---- */
+            uint32_t rel = 0, measured = 0;
+            uint32_t endV = 0;
+            bool stopAll = false;
+            forceFull = false;
+            {
+                uint32_t last = 0;      /* what ended the chain: 0xFFFF, 0xFFFE or nothing special */
+#pragma unroll 1
+                for ( ; measured < n; ++measured ) {
+                    const uint32_t y = rel - (uint32_t)__builtin_amdgcn_readlane( (int)loV, measured );   /* wraps in front of the window */
+                    if ( y > (uint32_t)__builtin_amdgcn_readlane( (int)widthV, measured ) ) break;        /* outside (never for slot 0) */
+                    const uint32_t u = sfl( shared.slot( measured ).at( 0, y ) );
+                    if ( u >= 0xFFFEu ) {
+                        last = u;
+                        break;
+                    }
+                    rel = u;
+                    endV = lane == measured ? u : endV;
+                }
+                forceFull = ( last == 0xFFFFu ) && ( measured == 0 );     /* a group longer than expected: the full span next */
+                stopAll = last == 0xFFFEu;                                /* end-of-block, no code or end of input inside this group */
+            }
+            if ( stopAll ) terminal = 1;
+            const uint32_t done = measured + ( stopAll ? 1u : 0u );
+            /* starts of the `done` groups (lane w: group g + w) -> the lanes of their group numbers; the window of 64 is
+             * written out when its last group is known, before the next window's first groups take its lanes */
+            uint32_t dV;
+            {
+                const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp( 0, (int)endV, 0x111, 0xF, 0xF, true );   /* row_shr:1 */
+                const uint32_t startV = lane == 0 ? 0u : before;
+                dV = endV - startV;
+                const uint32_t idx = ( lane - g ) & 63u;                  /* which of the unit's groups this lane stands for */
+                const uint32_t mine = p + (uint32_t)__shfl( (int)startV, (int)idx );
+                const uint32_t inWindow = 64u - ( g & 63u );              /* groups of the unit that still belong to g's window */
+                const uint32_t part = done < inWindow ? done : inWindow;
+                gposV = idx < part ? mine : gposV;
+                if ( done >= inWindow ) {
+                    if ( wave == 0 ) gpos[( g & ~63u ) + lane] = gposV;
+                    gposV = ( idx >= part && idx < done ) ? mine : gposV;
+                }
+            }
+            const uint32_t cur = p + rel;
+            /* ---- what the measured groups say about their tables (lane t = table t), once per unit: the longest and the
+             * shortest group of the table in this unit ---- */
+            {
+                uint32_t dMax = 0, dMin = 0xFFFFFFFFu;
+#pragma unroll 1
+                for ( uint32_t w = 0; w < measured; ++w ) {
+                    const uint32_t tw = (uint32_t)__builtin_amdgcn_readlane( (int)tV, w );
+                    const uint32_t dw = (uint32_t)__builtin_amdgcn_readlane( (int)dV, w );
+                    dMax = ( lane == tw && dw > dMax ) ? dw : dMax;
+                    dMin = ( lane == tw && dw < dMin ) ? dw : dMin;
+                }
+                if ( dMax != 0 ) {
+                    const bool first = estV == 0;      /* says nothing about the spread yet: assume the envelope's 12 % */
+                    const uint32_t midOld = first ? dMax : midV;
+                    const uint32_t offHi = dMax > midOld ? dMax - midOld : midOld - dMax;
+                    const uint32_t offLo = dMin > midOld ? dMin - midOld : midOld - dMin;
+                    const uint32_t off = offHi > offLo ? offHi : offLo;
+                    const int32_t centre = (int32_t)( ( dMax + dMin ) >> 1 );
+                    estV = ( first || dMax > estV ) ? dMax : estV - ( ( estV - dMax ) >> 2 );
+                    midV = first ? dMax : (uint32_t)( (int32_t)midV + ( centre - (int32_t)midV ) / 2 );
+                    devV = first ? ( dMax >> 3 ) + 8 : ( off > devV ? off : devV - ( ( devV - off + 3 ) >> 2 ) );
+                }
+            }
+            if ( ( ( g + done ) ^ g ) & ~63u ) {      /* next window of 64 selectors */
+                selV = selNext;
+                selNext = sel[( ( g + done ) & ~63u ) + 64 + lane];   /* may read past the block's selectors: never used */
+            }
+            g += done;
+            p = cur;
+            __syncthreads();       /* the slots are rebuilt next */
+            if ( stopAll ) break;
+        }
+        nGroups = g;
+        if ( wave == 0 && ( g & 63u ) != 0 && lane < ( g & 63u ) ) gpos[( g & ~63u ) + lane] = gposV;
+    }
+
+    if ( wave == 0 && lane == 0 ) {
+        const uint32_t fullGroups = terminal ? nGroups - 1 : nGroups;
+        BlockMeta mt;
+        mt.enc_off = start;
+        mt.enc_size = sh.hdr.enc_size;
+        mt.decoded_size = 0;
+        mt.out_off = 0;
+        mt.header_crc = sh.hdr.header_crc;
+        mt.computed_crc = 0xFFFFFFFFu;
+        mt.n = 0;
+        mt.orig_ptr = sh.hdr.orig_ptr;
+        mt.nsym = fullGroups * GROUP_SYMS;    /* k_hsym's last lane finishes nsym, enc_size and status of a terminal group */
+        mt.is_eos = sh.hdr.is_eos;
+        mt.is_eof = sh.hdr.is_eof;
+        mt.status = status;
+        mt.seg_stride = MIN_SEG_STRIDE;
+        mt.nseg = 0;
+        mt.walk_ok = 0;
+        mt.cycle_len = 0;
+        mt.nchain = 0;
+        mt.pad = 0;
+        meta[b] = mt;
+        HuffMeta hm;
+        hm.n_stored = fullGroups * GROUP_SYMS;
+        hm.symbol_count = sh.hdr.symbol_count;
+        hm.status = status;
+        hm.active = active;
+        hmeta[b] = hm;
+        ScanMeta sm;
+        sm.pos_base = posBase;
+        sm.size_bits = sizeBits;
+        sm.n_groups = nGroups;
+        sm.terminal = terminal;
+        sm.symbol_count = sh.hdr.symbol_count;
+        smeta[b] = sm;
+    }
+}
+
+/* =============================================================================================================
  * k_hscan_pc: the scan with TWO waves per block, a producer and a consumer.
  *
  * With one wave per block a group costs the sum of two dependent chains: J1 (stream read, length look-up, long-code pass)
@@ -866,7 +1186,7 @@ k_hscan_pc( const uint32_t* __restrict__ in_words,
         /* producer: the stream ring (words [wHi - 256, wHi) present, the next 64 on their way) and the code ranges of the
          * table it last produced for */
         uint32_t wHi = 0, pend = 0;
-        if ( wave == 1 ) pend = lane < nWords ? be32( words[lane] ) : 0u;
+        if ( wave == 1 && lane < nWords ) pend = words[lane];
         uint32_t lim[10] = {};
         uint32_t eobLo = 0, eobHi = 0, limT = 0xFFFFFFFFu;
         uint32_t lastS[2] = { 0, 0 };
@@ -891,7 +1211,8 @@ k_hscan_pc( const uint32_t* __restrict__ in_words,
         const auto produce = [&] ( uint32_t s, uint32_t t, uint32_t base, uint32_t rows, bool nearEnd ) {
             while ( ( base >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
                 ring_put( sh.ring, wHi + lane, pend );
-                pend = wHi + 64 + lane < nWords ? be32( words[wHi + 64 + lane] ) : 0u;
+                pend = 0;
+                        if ( wHi + 64 + lane < nWords ) pend = words[wHi + 64 + lane];
                 wHi += 64;
             }
             if ( t != limT ) {

@@ -194,6 +194,52 @@ def test_two_contexts_over_one_resident_input(native, oracle):
     a.close()
 
 
+def test_background_copy_overlaps_the_next_batch(native, oracle):
+    """mi355x_bz2_copy_output_begin/_end (the reader's per-context loop): the bytes of batch k are copied while batch k + 1
+    -- of a different size, so that the second output buffer is allocated and later grows -- is decoded; afterwards
+    both are intact, the output pointer names the batch finished last, and growing buffers change nothing."""
+    parts = [datagen.text_like(700_000, 61), datagen.random_bytes(1_900_000, 62), datagen.text_like(3_100_000, 63)]
+    raw = b"".join(parts)
+    enc = b"".join(datagen.compress(p, 9) for p in parts)
+    offs = native.find_magic(enc)
+    d = native.Decoder()
+    d.set_input(enc)
+    want, total = d.decode_batch(offs)
+    assert d.copy_output(0, total) == raw
+    cuts = [1, 3, len(offs)]                      # growing batches: 1 block, 3 blocks, all
+    pending = None
+    for round_ in range(2):
+        for n in cuts:
+            results, size = d.decode_batch(offs[:n])
+            assert results == want[:n]
+            if pending is not None:
+                d.copy_output_end()
+                assert bytes(pending[0])[:pending[1]] == raw[:pending[1]]
+            assert d.copy_output(0, size) == raw[:size]           # the synchronous form reads the same batch
+            pending = (d.copy_output_begin(0, size), size)
+            assert d.output_device_ptr() != 0
+    d.copy_output_end()
+    assert bytes(pending[0])[:pending[1]] == raw[:pending[1]]
+    with pytest.raises(native.Bz2Error):
+        d.copy_output_begin(0, total + 1)          # beyond the last batch's bytes
+    arrays = d.make_arrays(offs)
+    d.begin_batch(arrays[0], len(offs))
+    with pytest.raises(native.Bz2Error):
+        d.copy_output_begin(0, 1)                  # a batch is in flight: its bytes are not there yet
+    assert d.end_batch(arrays[1]) == total
+    d.close()
+
+
+def test_warmup(native):
+    """mi355x_bz2_warmup: optional, idempotent, and says so if the device does not exist."""
+    native.warmup(0, background=False)
+    native.warmup(0, background=False)
+    thread = native.warmup(0)
+    thread.join()
+    with pytest.raises(native.Bz2Error):
+        native.warmup(4096, background=False)
+
+
 @pytest.mark.parametrize("symbols", [1, 2, 15, 16, 17, 127, 128, 129, 255, 256])
 def test_alphabet_sizes_around_the_list_variants(native, oracle, dec, symbols):
     """k_mtf runs in two instances (128-entry and 256-entry lists) chosen by the block's symbol count; 16-entry groups
@@ -364,18 +410,20 @@ def bench_slice(native):
     return _slice["v"]
 
 
-@pytest.mark.parametrize("variant", ["scan-pc", "scan-1", "scan-2", "scan-4", "scan-8", "window"])
+@pytest.mark.parametrize("variant", ["scan-pc", "scan-1", "scan-2", "scan-4", "scan-8", "spec-4", "spec-8", "window"])
 def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
-    """Every form of the Huffman stage -- k_hscan_pc, k_hscan with 1, 2, 4 or 8 wavefronts per block (+ k_hsym) and the single-chain
-    k_huff -- against the oracle, whatever the batch size would select by itself: valid data of all kinds, streams no
+    """Every form of the Huffman stage -- k_hscan_pc, k_hscan with 1, 2, 4 or 8 wavefronts per block, k_hscan_spec with 4 or 8
+    (+ k_hsym) and the single-chain k_huff -- against the oracle, whatever the batch size would select by itself: valid data of all kinds, streams no
     libbz2 writes, one invalid stream per reference throw site, and seeded damage (every field of every record)."""
     if variant == "window":
         monkeypatch.setenv("MI355X_BZ2_HUFF", "window")
     else:
-        # scan-pc: producer + consumer wave per block (k_hscan_pc), scan-N: N cooperating waves (k_hscan<N>)
+        # scan-pc: producer + consumer wave per block (k_hscan_pc), scan-N: N cooperating waves (k_hscan<N>),
+        # spec-N: N waves on N consecutive groups (k_hscan_spec<N>)
         monkeypatch.setenv("MI355X_BZ2_HUFF", "scan")
         monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1" if variant == "scan-pc" else variant.split("-")[1])
         monkeypatch.setenv("MI355X_BZ2_SCAN_PC", "1" if variant == "scan-pc" else "0")
+        monkeypatch.setenv("MI355X_BZ2_SCAN_SPEC", "1" if variant.startswith("spec") else "0")
     d = native.Decoder(flags=native.Decoder.KEEP_STAGES)
     try:
         corpus = datagen.corpus_small()
