@@ -994,9 +994,12 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             ScanMeta* const smeta = c->dSmeta + first;
             HuffTables* const htab = c->dHtab + first;
             uint32_t* const gpos = c->dGpos + (size_t)first * GPOS_STRIDE;
-            /* wavefronts per block: one when the batch fills the GPU by itself, four or eight (speculative builds of
-             * the next groups, see bz2_hscan.hip.h) when few blocks have to be through quickly */
-            const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves : ( n <= 64 ? 8u : ( n <= 1280 ? 4u : 1u ) );
+            /* wavefronts per block: one when the batch fills the GPU by itself; four or eight, each on a group of its own
+             * (k_hscan_spec, bz2_hscan.hip.h), when few blocks have to be through quickly (their LDS, one build per wave,
+             * allows 4 and 2 blocks per CU).  Measured: sixteen waves gain nothing over eight (the chain from group to
+             * group and the barriers grow with the waves); eight are faster than four for ONE batch of 320 blocks (15 vs
+             * 18 ms) but slower when four such batches run side by side (14.5 vs 13.4 ms per batch) */
+            const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves : ( n <= 128 ? 8u : ( n <= 1280 ? 4u : 1u ) );
             const auto* const inWords = reinterpret_cast<const uint32_t*>( inBase );
             if ( scanWaves >= 8 && scanSpec ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,

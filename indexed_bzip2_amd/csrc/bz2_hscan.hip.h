@@ -118,16 +118,17 @@ struct ScanShared
 /** Stream word `index` (relative to the block's base word), as loaded (little-endian view of the big-endian stream), into
  * the ring: high half of entry `index`, low half of entry `index - 1`, and their mirrors.  The byte swap is done here and
  * not where the word was loaded: the load is issued one refill ahead, and a swap behind it would wait for the memory. */
+template<uint32_t RING = SCAN_RING_ENTRIES>
 __device__ __forceinline__ void
 ring_put( uint32_t* ring, uint32_t index, uint32_t raw )
 {
     const uint32_t value = be32( raw );
-    const uint32_t e1 = index & ( SCAN_RING_ENTRIES - 1 );
-    const uint32_t e0 = ( index - 1 ) & ( SCAN_RING_ENTRIES - 1 );
+    const uint32_t e1 = index & ( RING - 1 );
+    const uint32_t e0 = ( index - 1 ) & ( RING - 1 );
     ring[2 * e1 + 1] = value;
     ring[2 * e0] = value;
-    if ( e1 < SCAN_RING_MIRROR ) ring[2 * ( SCAN_RING_ENTRIES + e1 ) + 1] = value;
-    if ( e0 < SCAN_RING_MIRROR ) ring[2 * ( SCAN_RING_ENTRIES + e0 )] = value;
+    if ( e1 < SCAN_RING_MIRROR ) ring[2 * ( RING + e1 ) + 1] = value;
+    if ( e0 < SCAN_RING_MIRROR ) ring[2 * ( RING + e0 )] = value;
 }
 
 /** Barrier between the waves that share a build; a single wave only has to order its own LDS traffic. */
@@ -152,7 +153,7 @@ scan_sync()
  * endRows positions, where the 50-symbol group that starts there ends (k_hscan_spec) */
 constexpr int SCAN_ALL = 0, SCAN_J1_ONLY = 1, SCAN_LEVELS_ONLY = 2, SCAN_ENDS = 3;
 
-template<uint32_t K, uint32_t RW, bool NEAR_END, int PART = SCAN_ALL>
+template<uint32_t K, uint32_t RW, bool NEAR_END, int PART = SCAN_ALL, uint32_t RING = SCAN_RING_ENTRIES>
 __device__ __forceinline__ void
 scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p, uint32_t sizeBits,
             const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane, uint32_t wave,
@@ -179,7 +180,7 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
     {
         /* 64 stream bits from the lane's word on: one 8-byte read per row at a fixed distance from the first row's */
         const uint32_t a0 = p + first;
-        const uint64_t* const w = reinterpret_cast<const uint64_t*>( ring ) + ( ( a0 >> 5 ) & ( SCAN_RING_ENTRIES - 1 ) );
+        const uint64_t* const w = reinterpret_cast<const uint64_t*>( ring ) + ( ( a0 >> 5 ) & ( RING - 1 ) );
         const uint32_t sh = a0 & 31u;
 #pragma unroll
         for ( uint32_t j = 0; j < RW; ++j ) {
@@ -555,7 +556,7 @@ scan_rows_per_wave( uint32_t rows )
     return rw <= 8 ? ( 8u < MAX ? 8u : MAX ) : ( rw <= 10 ? ( 10u < MAX ? 10u : MAX ) : ( rw <= 12 ? ( 12u < MAX ? 12u : MAX ) : MAX ) );
 }
 
-template<uint32_t K, int PART = SCAN_ALL>
+template<uint32_t K, int PART = SCAN_ALL, uint32_t RING = SCAN_RING_ENTRIES>
 __device__ __forceinline__ void
 scan_build_rows( uint32_t rw, bool nearEnd, ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p,
                  uint32_t sizeBits, const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool one, uint32_t lane,
@@ -564,15 +565,15 @@ scan_build_rows( uint32_t rw, bool nearEnd, ScanSlot& slot, const uint8_t* lenlu
     constexpr uint32_t MAX = SCAN_ROWS / K;
 #define SCAN_CASE( n ) \
     if constexpr ( ( n ) <= MAX ) { \
-        if ( rw == ( n ) ) { scan_build<K, ( n ), false, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase ); return; } \
+        if ( rw == ( n ) ) { scan_build<K, ( n ), false, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase ); return; } \
     }
     if ( nearEnd ) {
-        scan_build<K, MAX, true, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
+        scan_build<K, MAX, true, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
         return;
     }
     SCAN_CASE( 1 ) SCAN_CASE( 2 ) SCAN_CASE( 3 ) SCAN_CASE( 4 ) SCAN_CASE( 5 ) SCAN_CASE( 6 ) SCAN_CASE( 8 ) SCAN_CASE( 10 )
     SCAN_CASE( 12 )
-    scan_build<K, MAX, false, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
+    scan_build<K, MAX, false, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
 #undef SCAN_CASE
 }
 
@@ -801,14 +802,20 @@ k_hscan( const uint32_t* __restrict__ in_words,
 template<uint32_t K>
 struct SpecShared
 {
+    static constexpr uint32_t RING = K > 8 ? 2 * SCAN_RING_ENTRIES : SCAN_RING_ENTRIES;   /* stream words around the unit */
     ScanShared<1> s;          /* tables, ring, header; its slot is wave 0's */
     ScanSlot more[K - 1];     /* the slots of waves 1 .. K - 1 */
+    uint32_t wideRing[K > 8 ? 2 * ( RING + SCAN_RING_MIRROR ) : 2];   /* sixteen groups reach further than s.ring holds */
+
+    __device__ __forceinline__ uint32_t* ring() { return K > 8 ? wideRing : s.ring; }
 
     __device__ __forceinline__ ScanSlot& slot( uint32_t w ) { return w == 0 ? s.slot[0] : more[w - 1]; }
 };
 
-constexpr uint32_t SPEC_REACH = 3400;   /* bits in front of the current position that a unit may look (the stream ring holds
-                                           8 192, of which a build needs 1 120 behind its start) */
+/* bits in front of the current position that a unit may look: the stream ring holds 32 bits per entry, a build needs
+ * 1 120 bits behind its start, refills come in pieces of 2 048 bits, and the current position must stay inside */
+template<uint32_t K>
+constexpr uint32_t SPEC_REACH = 32 * SpecShared<K>::RING - 4700;
 
 template<uint32_t K>
 __global__ __launch_bounds__( 64 * K ) void
@@ -892,14 +899,14 @@ k_hscan_spec( const uint32_t* __restrict__ in_words,
                 const uint32_t slack = dev + ( dev >> 2 ) + 2;
                 const uint32_t stepLo = mid > slack + 50 ? mid - slack : 50u;      /* 50 symbols are at least 50 bits */
                 const uint32_t stepHi = mid + slack;
-                /* exclusive prefix sums over the first lanes (K <= 8: inside one row of 16 lanes) */
+                /* exclusive prefix sums over the first lanes (K <= 16: inside one row of 16 lanes) */
                 uint32_t accLo = stepLo, accHi = stepHi;
 #define SPEC_SCAN_STEP( k ) \
                 if constexpr ( ( k ) < K ) { \
                     accLo += (uint32_t)__builtin_amdgcn_update_dpp( 0, (int)accLo, 0x110 + ( k ), 0xF, 0xF, true );   /* row_shr:k, 0 shifted in */ \
                     accHi += (uint32_t)__builtin_amdgcn_update_dpp( 0, (int)accHi, 0x110 + ( k ), 0xF, 0xF, true ); \
                 }
-                SPEC_SCAN_STEP( 1 ) SPEC_SCAN_STEP( 2 ) SPEC_SCAN_STEP( 4 )
+                SPEC_SCAN_STEP( 1 ) SPEC_SCAN_STEP( 2 ) SPEC_SCAN_STEP( 4 ) SPEC_SCAN_STEP( 8 )
 #undef SPEC_SCAN_STEP
                 accLo -= stepLo;
                 accHi -= stepHi;
@@ -907,7 +914,7 @@ k_hscan_spec( const uint32_t* __restrict__ in_words,
                 widthV = accHi - accLo;
                 rowsV = scan_rows_per_wave<1>( ( widthV + need + 24 + 63 ) >> 6 );
                 const bool ok = ( lane < K ) && ( gw < nSel ) && ( gw < MAX_SCAN_GROUPS ) && !( ( tune & 1u ) && lane > 0 )
-                                && ( est != 0 ) && ( widthV + need + 24 <= SCAN_MAX_SPAN ) && ( accHi <= SPEC_REACH )
+                                && ( est != 0 ) && ( widthV + need + 24 <= SCAN_MAX_SPAN ) && ( accHi <= SPEC_REACH<K> )
                                 && ( p + accLo + SCAN_MAX_SPAN + 32 <= sizeBits );
                 const uint64_t okMask = __ballot( ok );
                 n = (uint32_t)__builtin_ctzll( ~okMask );            /* slots 0 .. n - 1 are usable */
@@ -927,7 +934,7 @@ k_hscan_spec( const uint32_t* __restrict__ in_words,
                 if ( needWord > wHi ) {
                     while ( needWord > wHi ) {
                         if ( ( ( wHi >> 6 ) & ( K - 1 ) ) == wave ) {
-                            ring_put( sh.ring, wHi + lane, pend );
+                            ring_put<SpecShared<K>::RING>( shared.ring(), wHi + lane, pend );
                             pend = 0;
                             if ( wHi + 64 * K + lane < nWords ) pend = words[wHi + 64 * K + lane];
                         }
@@ -959,7 +966,7 @@ k_hscan_spec( const uint32_t* __restrict__ in_words,
                     }
                     lastS = S;
                 }
-                scan_build_rows<1, SCAN_ENDS>( myRows, full && nearEnd, mySlot, sh.lenlut[myT], sh.ring, p + myLo, sizeBits, lim,
+                scan_build_rows<1, SCAN_ENDS, SpecShared<K>::RING>( myRows, full && nearEnd, mySlot, sh.lenlut[myT], shared.ring(), p + myLo, sizeBits, lim,
                                                eobLo, eobHi, false, lane, 0, ( myWidth >> 6 ) + 1, myLo );
             }
             __syncthreads();
