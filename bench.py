@@ -136,17 +136,16 @@ def main():
                     help="secondary figure only: compressed bytes already resident in HBM before the timed region")
     ap.add_argument("--contexts", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="decoder contexts used in turn: step k+1 is queued on the next context before step k is "
-                         "finished, so its transfer and its latency-bound first kernels overlap the kernels of step k.  "
-                         "0 = 3 for one GPU (2 560 blocks per step keep the GPU busy; the third context hides the H2D "
-                         "copy: 82 instead of 87 ms per step) and 4 for N > 1, where a rank's share of the file is small "
-                         "and a step's duration is the latency of its largest block")
+                         "finished, so the latency-bound first kernels of one step overlap the throughput kernels of the "
+                         "others.  0 = 4 (measured on one box, 2 560 blocks per step: 3 contexts 74.5 ms, 4: 72.1, 5: 83.6; "
+                         "a rank's share of the file at 8 GPUs, 310 blocks: 4 contexts 14.0 ms, 5: 15.7)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on ONE GPU: ranks share cuda:0 and extents travel via host memory")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.contexts == 0:
-        args.contexts = 3 if world_env == 1 else 4
+        args.contexts = 4
     # every decoder context drives up to 4 HIP streams: without this the runtime maps them onto 4 hardware queues and
     # streams that share a queue serialize (must be set before the HIP runtime starts)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.contexts))
@@ -279,19 +278,25 @@ def main():
 
     def run_steps(count, resident=False):
         """`count` passes of the hot path, each through the C ABI with preallocated arrays (no per-block Python
-        objects).  A pass = queue the H2D copy of the compressed bytes, then the batch.  With two contexts step k+1 is
-        queued before step k is finished; all `count` steps begin and end inside this call."""
+        objects).  A pass = the H2D copy of the compressed bytes, then the batch.  With several contexts step k+1 is
+        queued before step k is finished, and the copy for a context's next step is queued as soon as its current step
+        has been launched (into the context's second input buffer); all `count` copies and steps begin and end inside
+        this call."""
         gpu_ms = 0.0
         depth = len(decs)
+        prefetch = os.environ.get("BENCH_NO_PREFETCH") != "1"     # development: copy and batch of a step strictly in turn
         for k in range(count + depth):
             if k >= depth:                       # step k - depth holds the context that step k needs
                 finish(k - depth)
                 gpu_ms += decs[(k - depth) % depth].pipeline_ms()
             if k < count:
                 d = decs[k % depth]
-                if not resident:
+                if not resident and (k < depth or not prefetch):
                     d.set_input_host_async(host_ptr, my_bytes, keepalive=host_in)
                 d.begin_batch(offs_c, n_blocks)
+                if not resident and prefetch and k + depth < count:
+                    # the bytes of this context's NEXT step (step k + depth): their copy runs beside the kernels of this one
+                    d.set_input_host_async(host_ptr, my_bytes, keepalive=host_in)
         return gpu_ms
 
     run_steps(max(len(decs), args.warmup - 1))   # warm-up; also sizes the scratch of every context
@@ -361,8 +366,8 @@ def main():
                        "decoder_contexts": len(decs),
                        "input_resident_in_hbm": bool(args.resident), "output_left_in_hbm": True,
                        "step": ("compressed bytes resident in HBM -> decoded bytes in HBM" if args.resident else
-                                "compressed bytes in page-locked host memory -> H2D (queued on the decoder's stream, overlaps "
-                                "the other context's kernels) -> decoded bytes in HBM"),
+                                "compressed bytes in page-locked host memory -> H2D (on the context's input stream, beside the "
+                                "kernels of the step in front of it) -> decoded bytes in HBM"),
                        "block_offsets": "known before the timed region (index / finder thread); the same offsets from the "
                                         "GPU magic scan k_find_magic take %.2f ms (not part of a step)" % scan_ms},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -131,10 +131,11 @@ const char* mi355x_bz2_last_error( const mi355x_bz2_ctx* ctx );
  * copy and no swap pass).  _host copies H2D (pageable or page-locked host memory) and waits; _device copies D2D from a
  * device pointer that is only read during the call (size need not be padded).  The caller's buffer may be freed
  * afterwards; the copy costs `size` bytes of HBM.
- * _host_async only QUEUES the H2D copy on the context's stream (in 64-MiB pieces) and returns: the next
- * decode_batch[_begin] on this context is ordered behind it, so the transfer overlaps with whatever other contexts are
- * running.  `bytes` should be page-locked (hipHostMalloc / hipHostRegister) and must stay valid until that batch's
- * decode_batch_end has returned.
+ * _host_async only QUEUES the H2D copy (in 64-MiB pieces, on a stream of the context's own) and returns: the next
+ * decode_batch[_begin] on this context is ordered behind it, so the transfer overlaps with whatever is running.  It may
+ * be called while a batch is in flight on this context -- these are then the bytes of the NEXT batch, copied into a second
+ * buffer beside the kernels of the current one (what bench.py does).  `bytes` should be page-locked (hipHostMalloc /
+ * hipHostRegister) and must stay valid until that batch's decode_batch_end has returned.
  * Replaces the BitReader/SharedFileReader clone + pread of BZ2BlockFetcher.hpp:89-90. */
 int mi355x_bz2_set_input_host( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );
 int mi355x_bz2_set_input_host_async( mi355x_bz2_ctx* ctx, const uint8_t* bytes, uint64_t size );

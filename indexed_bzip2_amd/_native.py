@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355x_bz2.so")
+# (MI355X_BZ2_LIBRARY: development only, an A/B build of the same ABI)
+LIB_PATH = os.environ.get("MI355X_BZ2_LIBRARY") or os.path.join(_HERE, "libmi355x_bz2.so")
 
 MAGIC_BLOCK = 0x314159265359
 MAGIC_EOS = 0x177245385090

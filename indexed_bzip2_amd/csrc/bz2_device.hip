@@ -85,8 +85,19 @@ struct mi355x_bz2_ctx
     std::mutex mutex;
 
     /* input */
-    uint8_t* dInOwned{ nullptr };
-    uint64_t dInOwnedCapacity{ 0 };
+    /* ctx-owned copies of the input.  A copy queued while a batch is in flight (set_input_host_async: the bytes of the
+     * NEXT batch, beside the kernels of this one) goes into the second buffer, on a stream of its own */
+    struct InBuffer
+    {
+        uint8_t* bytes{ nullptr };
+        uint64_t capacity{ 0 };
+    };
+    InBuffer in[2];
+    int inCurrent{ 0 };                 /* the buffer c->dIn points into, if it is ctx-owned */
+    int inFlight{ -1 };                 /* the buffer the batch in flight reads, -1 if none of the two */
+    hipStream_t inStream{ nullptr };
+    hipEvent_t inReady{ nullptr };      /* behind the last copy queued on inStream */
+    bool inPending{ false };            /* a copy has been queued that no batch has been ordered behind yet */
     const uint8_t* dIn{ nullptr };
     uint64_t inSize{ 0 };
     std::shared_ptr<InputUpload> upload;   /* set while / after a streamed copy of the input */
@@ -132,6 +143,9 @@ struct mi355x_bz2_ctx
     uint32_t* dWalkBlk{ nullptr };    /* [MAX_GROUPS][cap + 16] */
     uint32_t* dWalkPre{ nullptr };
     uint32_t* hSlotOf{ nullptr };     /* pinned: original index -> slot */
+    uint32_t* dSlotOf{ nullptr };
+    uint64_t* dTotals{ nullptr };     /* k_offsets: {total decoded bytes, does not fit} */
+    uint64_t* hTotals{ nullptr };     /* pinned */
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
 
@@ -150,12 +164,12 @@ struct mi355x_bz2_ctx
     int outLastCopy{ 0 };
     hipStream_t copyStream{ nullptr };
     uint8_t* dOut{ nullptr };             /* == out[outCurrent].bytes */
+    uint64_t outSizeHint{ 0 };            /* the largest batch output so far */
 
     /* mi355x_bz2_find_magic_device: a stream and buffers of its own, so that a scan neither queues behind a batch nor
      * stops one (hipFree waits for the whole device) */
     std::mutex scanMutex;
     hipStream_t scanStream{ nullptr };
-    hipEvent_t scanOrder{ nullptr };
     uint64_t* dScanFound{ nullptr };
     uint32_t* dScanCounter{ nullptr };
     uint64_t outSize{ 0 };
@@ -262,6 +276,7 @@ freeScratch( mi355x_bz2_ctx* c, bool now = true )
     c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegOff = nullptr; c->dSegCont = nullptr;
     c->dChain = nullptr; c->dStash = nullptr; c->dPlan = nullptr; c->dWalkBlk = nullptr; c->dWalkPre = nullptr;
     c->hOrder = nullptr; c->hSlotOf = nullptr; c->hMeta = nullptr; c->hOffsets = nullptr;
+    c->dSlotOf = nullptr; c->dTotals = nullptr; c->hTotals = nullptr;
     c->capacity = 0;
 }
 
@@ -306,10 +321,13 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t oPlan = reserve( deviceBytes, MAX_GROUPS * sizeof( WalkPlan ) );
     const size_t oWalkBlk = reserve( deviceBytes, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) );
     const size_t oWalkPre = reserve( deviceBytes, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) );
+    const size_t oSlotOf = reserve( deviceBytes, (size_t)cap * sizeof( uint32_t ) );
+    const size_t oTotals = reserve( deviceBytes, 2 * sizeof( uint64_t ) );
     const size_t hOrderAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t hSlotOfAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t hMetaAt = reserve( hostBytes, (size_t)cap * sizeof( BlockMeta ) );
     const size_t hOffsetsAt = reserve( hostBytes, (size_t)cap * sizeof( uint64_t ) );
+    const size_t hTotalsAt = reserve( hostBytes, 2 * sizeof( uint64_t ) );
 
     const auto tAlloc = std::chrono::steady_clock::now();
     HIP_TRY( c, hipMalloc( &c->dScratch, deviceBytes ) );
@@ -342,10 +360,13 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dPlan = reinterpret_cast<WalkPlan*>( d + oPlan );
     c->dWalkBlk = reinterpret_cast<uint32_t*>( d + oWalkBlk );
     c->dWalkPre = reinterpret_cast<uint32_t*>( d + oWalkPre );
+    c->dSlotOf = reinterpret_cast<uint32_t*>( d + oSlotOf );
+    c->dTotals = reinterpret_cast<uint64_t*>( d + oTotals );
     c->hOrder = reinterpret_cast<uint32_t*>( h + hOrderAt );
     c->hSlotOf = reinterpret_cast<uint32_t*>( h + hSlotOfAt );
     c->hMeta = reinterpret_cast<BlockMeta*>( h + hMetaAt );
     c->hOffsets = reinterpret_cast<uint64_t*>( h + hOffsetsAt );
+    c->hTotals = reinterpret_cast<uint64_t*>( h + hTotalsAt );
     c->capacity = cap;
     c->scratchBytes = deviceBytes;
     c->scratchHostBytes = hostBytes;
@@ -548,12 +569,14 @@ mi355x_bz2_destroy( mi355x_bz2_ctx* c )
     freeScratch( c );
     freeRetired( c );
     c->upload.reset();   /* joins the copy thread (of the owner; sharers only drop their reference) before the memory goes */
-    (void)hipFree( c->dInOwned );
+    if ( c->inStream ) (void)hipStreamSynchronize( c->inStream );
+    for ( auto& buffer : c->in ) (void)hipFree( buffer.bytes );
+    if ( c->inReady ) (void)hipEventDestroy( c->inReady );
+    if ( c->inStream ) (void)hipStreamDestroy( c->inStream );
     if ( c->scanStream ) {
         (void)hipStreamSynchronize( c->scanStream );
         (void)hipStreamDestroy( c->scanStream );
     }
-    if ( c->scanOrder ) (void)hipEventDestroy( c->scanOrder );
     (void)hipFree( c->dScanFound );
     (void)hipFree( c->dScanCounter );
     if ( c->copyStream ) (void)hipStreamSynchronize( c->copyStream );
@@ -590,16 +613,18 @@ namespace
 {
 /** Room for `size` input bytes + padding in the ctx-owned copy. */
 int
-reserveInput( mi355x_bz2_ctx* c, uint64_t size )
+reserveInput( mi355x_bz2_ctx* c, int which, uint64_t size )
 {
+    auto& buffer = c->in[which];
     const uint64_t padded = ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256;
-    if ( padded > c->dInOwnedCapacity ) {
-        HIP_TRY( c, hipStreamSynchronize( c->stream ) );
-        (void)hipFree( c->dInOwned );
-        c->dInOwned = nullptr;
-        c->dInOwnedCapacity = 0;
-        HIP_TRY( c, hipMalloc( &c->dInOwned, padded ) );
-        c->dInOwnedCapacity = padded;
+    if ( padded > buffer.capacity ) {
+        /* nothing reads this buffer: the batch in flight, if any, reads the other one */
+        if ( c->inStream ) HIP_TRY( c, hipStreamSynchronize( c->inStream ) );
+        retire( c, buffer.bytes, buffer.capacity, false, padded );
+        buffer.bytes = nullptr;
+        buffer.capacity = 0;
+        HIP_TRY( c, hipMalloc( &buffer.bytes, padded ) );
+        buffer.capacity = padded;
     }
     return MI355X_BZ2_OK;
 }
@@ -638,26 +663,32 @@ awaitInput( mi355x_bz2_ctx* c, uint64_t needed, const uint8_t** base, uint64_t* 
     return MI355X_BZ2_OK;
 }
 
-/** Reserve the ctx-owned input copy and queue `size` bytes into it (host or device source) on the ctx stream, zero padded;
- * no wait.  Copies of more than 64 MiB from the host go in pieces, so that the first kernels of another context's batch
- * are not queued behind one long transfer. */
+/** Queue `size` bytes (host or device source) into a ctx-owned input copy, zero padded, on the input stream; no wait.
+ * The next decode_batch_begin is ordered behind the copy.  While a batch is in flight the copy goes into the buffer
+ * that batch does not read.  Copies of more than 64 MiB go in pieces, so that what other streams move is not queued
+ * behind one long transfer. */
 int
 queueInput( mi355x_bz2_ctx* c, const void* bytes, uint64_t size, hipMemcpyKind kind )
 {
     HIP_TRY( c, hipSetDevice( c->device ) );
     c->upload.reset();
-    const int rc = reserveInput( c, size );
+    if ( c->inStream == nullptr ) HIP_TRY( c, hipStreamCreateWithFlags( &c->inStream, hipStreamNonBlocking ) );
+    if ( c->inReady == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &c->inReady, hipEventDisableTiming ) );
+    const int which = ( c->pendingBlocks != 0 && c->inFlight >= 0 ) ? c->inFlight ^ 1 : c->inCurrent;
+    const int rc = reserveInput( c, which, size );
     if ( rc != MI355X_BZ2_OK ) return rc;
-    const uint64_t padded = c->dInOwnedCapacity;
-    HIP_TRY( c, hipMemsetAsync( c->dInOwned + ( size & ~uint64_t( 255 ) ), 0,
-                                ( ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256 ) - ( size & ~uint64_t( 255 ) ), c->stream ) );
-    (void)padded;
+    uint8_t* const target = c->in[which].bytes;
+    HIP_TRY( c, hipMemsetAsync( target + ( size & ~uint64_t( 255 ) ), 0,
+                                ( ( ( size + 255 ) & ~uint64_t( 255 ) ) + 256 ) - ( size & ~uint64_t( 255 ) ), c->inStream ) );
     constexpr uint64_t PIECE = uint64_t( 64 ) << 20;
     for ( uint64_t at = 0; at < size; at += PIECE ) {
-        HIP_TRY( c, hipMemcpyAsync( c->dInOwned + at, static_cast<const uint8_t*>( bytes ) + at, std::min( PIECE, size - at ),
-                                    kind, c->stream ) );
+        HIP_TRY( c, hipMemcpyAsync( target + at, static_cast<const uint8_t*>( bytes ) + at, std::min( PIECE, size - at ),
+                                    kind, c->inStream ) );
     }
-    c->dIn = c->dInOwned;
+    HIP_TRY( c, hipEventRecord( c->inReady, c->inStream ) );
+    c->inPending = true;
+    c->inCurrent = which;
+    c->dIn = target;
     c->inSize = size;
     return MI355X_BZ2_OK;
 }
@@ -668,9 +699,13 @@ mi355x_bz2_set_input_host( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64_t siz
 {
     if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex );
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "set_input_host: a batch is in flight";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
     const int rc = queueInput( c, bytes, size, hipMemcpyHostToDevice );
     if ( rc != MI355X_BZ2_OK ) return rc;
-    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    HIP_TRY( c, hipStreamSynchronize( c->inStream ) );
     return MI355X_BZ2_OK;
 }
 
@@ -679,10 +714,7 @@ mi355x_bz2_set_input_host_async( mi355x_bz2_ctx* c, const uint8_t* bytes, uint64
 {
     if ( c == nullptr || ( bytes == nullptr && size > 0 ) ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     const std::scoped_lock lock( c->mutex );
-    if ( c->pendingBlocks != 0 ) {
-        c->lastError = "set_input_host_async: a batch is in flight";
-        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
-    }
+    /* a batch may be in flight: these are the bytes of the next one */
     return queueInput( c, bytes, size, hipMemcpyHostToDevice );
 }
 
@@ -697,9 +729,12 @@ mi355x_bz2_set_input_host_streamed( mi355x_bz2_ctx* c, const uint8_t* bytes, uin
     }
     HIP_TRY( c, hipSetDevice( c->device ) );
     c->upload.reset();
-    (void)hipFree( c->dInOwned );      /* the streamed copy owns its buffers */
-    c->dInOwned = nullptr;
-    c->dInOwnedCapacity = 0;
+    if ( c->inStream ) HIP_TRY( c, hipStreamSynchronize( c->inStream ) );
+    for ( auto& buffer : c->in ) {      /* the streamed copy owns its buffers */
+        (void)hipFree( buffer.bytes );
+        buffer = {};
+    }
+    c->inPending = false;
     auto upload = std::make_shared<InputUpload>();
     upload->total = size;
     upload->device = c->device;
@@ -776,9 +811,13 @@ mi355x_bz2_set_input_device( mi355x_bz2_ctx* c, const void* deviceBytes, uint64_
     const std::scoped_lock lock( c->mutex );
     /* The kernels read whole 16-byte windows without bounds checks, so the bytes are copied (device to device, once)
      * into ctx-owned memory that is zero padded past the end. */
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "set_input_device: a batch is in flight";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
     const int rc = queueInput( c, deviceBytes, size, hipMemcpyDeviceToDevice );
     if ( rc != MI355X_BZ2_OK ) return rc;
-    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    HIP_TRY( c, hipStreamSynchronize( c->inStream ) );
     return MI355X_BZ2_OK;
 }
 
@@ -795,7 +834,12 @@ mi355x_bz2_share_input( mi355x_bz2_ctx* c, mi355x_bz2_ctx* from )
         c->lastError = "share_input: a batch is in flight";
         return MI355X_BZ2_ERR_INVALID_ARGUMENT;
     }
-    c->dIn = from->dIn;      /* not owned: mi355x_bz2_destroy frees dInOwned only */
+    if ( from->inReady != nullptr ) {
+        /* a copy that `from` has queued (set_input_host_async): this context's batches come behind it too */
+        HIP_TRY( c, hipSetDevice( c->device ) );
+        HIP_TRY( c, hipStreamWaitEvent( c->stream, from->inReady, 0 ) );
+    }
+    c->dIn = from->dIn;      /* not owned: mi355x_bz2_destroy frees this context's own copies only */
     c->inSize = from->inSize;
     c->upload = from->upload;
     return MI355X_BZ2_OK;
@@ -837,6 +881,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     const bool traceBegin = std::getenv( "MI355X_BZ2_READER_TRACE" ) != nullptr;
     const auto tBegin = std::chrono::steady_clock::now();
     int rc = ensureScratch( c, n );
+    if ( rc != MI355X_BZ2_OK ) return rc;
+    /* the output buffer of this batch (see the end of this function), chosen and, if need be, allocated before anything
+     * is queued: growing it waits for the stream */
+    rc = ensureOutput( c, std::max<uint64_t>( (uint64_t)n * 900000u, c->outSizeHint ) );
     if ( rc != MI355X_BZ2_OK ) return rc;
     const auto tScratch = std::chrono::steady_clock::now();
     /* with a streamed copy of the input this batch needs it up to where its last block can end (a block of 900 000
@@ -931,9 +979,15 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         for ( uint32_t k = 0; k < groupCount[g]; ++k ) order[k] = groupCount[g] - 1 - k;   /* group-relative slot */
     }
     for ( auto& bits : c->launched ) bits = 0;
+    if ( c->inPending ) {
+        HIP_TRY( c, hipStreamWaitEvent( c->stream, c->inReady, 0 ) );
+        c->inPending = false;
+    }
+    c->inFlight = ( inBase == c->in[0].bytes && inBase != nullptr ) ? 0 : ( ( inBase == c->in[1].bytes && inBase != nullptr ) ? 1 : -1 );
     HIP_TRY( c, hipEventRecord( c->evStep[0], c->stream ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOffsets, c->hOffsets, (size_t)n * sizeof( uint64_t ), hipMemcpyHostToDevice, c->stream ) );
     HIP_TRY( c, hipMemcpyAsync( c->dOrder, c->hOrder, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
+    HIP_TRY( c, hipMemcpyAsync( c->dSlotOf, c->hSlotOf, (size_t)n * sizeof( uint32_t ), hipMemcpyHostToDevice, c->stream ) );
     HIP_TRY( c, hipEventRecord( c->evStep[1], c->stream ) );
     auto streamOf = [&] ( int g ) { return g == expensiveGroup ? c->gstream[MAX_GROUPS - 1] : c->gstream[g]; };
     for ( int g = 1; g < nGroups; ++g ) {
@@ -1052,8 +1106,21 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         HIP_TRY( c, hipStreamWaitEvent( c->stream, c->evGroupDone[g], 0 ) );
     }
 
-    /* sizes -> host: output offsets are an exclusive scan of the decoded sizes IN INPUT ORDER (ragged, gap-free) */
+    /* Output offsets = exclusive scan of the decoded sizes IN INPUT ORDER (ragged, gap-free), on the device; then the
+     * expansion and the CRC, queued right behind: no round trip to the host in the middle of a batch.  The output buffer
+     * is chosen now, for the size that blocks of the usual compressors have at most (900 000 bytes each); if these
+     * decode to more, k_offsets says so, the two kernels do nothing and decode_batch_end repeats them with a buffer of
+     * the right size. */
+    hipLaunchKernelGGL( k_offsets, dim3( 1 ), dim3( OFFSETS_THREADS ), 0, c->stream, c->dMeta, c->dSlotOf, n,
+                        c->out[c->outCurrent].capacity, c->dTotals );
+    TIMED_LAUNCH( c, 0, c->stream, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut,
+                  c->dTotals + 1 );
+    TIMED_LAUNCH( c, 0, c->stream, 9, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc,
+                  c->dTotals + 1 );
+    HIP_TRY( c, hipEventRecord( c->evStep[2], c->stream ) );
+    HIP_TRY( c, hipGetLastError() );
     HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
+    HIP_TRY( c, hipMemcpyAsync( c->hTotals, c->dTotals, 2 * sizeof( uint64_t ), hipMemcpyDeviceToHost, c->stream ) );
     c->pendingBlocks = n;
     c->pendingGroups = nGroups;
     c->pendingExpensive = expensiveGroup;
@@ -1081,21 +1148,29 @@ mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* c, mi355x_bz2_block_result* results
     int rc = MI355X_BZ2_OK;
     HIP_TRY( c, hipSetDevice( c->device ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
-    uint64_t total = 0;
-    for ( uint32_t i = 0; i < n; ++i ) {
-        BlockMeta& m = c->hMeta[c->hSlotOf[i]];
-        m.out_off = total;
-        if ( m.walk_ok ) total += m.decoded_size;
+    uint64_t total = c->hTotals[0];
+    if ( c->hTotals[1] != 0 ) {
+        /* the bytes did not fit into the buffer chosen in decode_batch_begin (blocks that decode to more than 900 000
+         * bytes each): offsets on the host, a buffer of the right size, expansion and CRC once more */
+        total = 0;
+        for ( uint32_t i = 0; i < n; ++i ) {
+            BlockMeta& m = c->hMeta[c->hSlotOf[i]];
+            m.out_off = total;
+            if ( m.walk_ok ) total += m.decoded_size;
+        }
+        rc = ensureOutput( c, total );
+        if ( rc != MI355X_BZ2_OK ) return rc;
+        HIP_TRY( c, hipMemcpyAsync( c->dMeta, c->hMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) );
+        TIMED_LAUNCH( c, 0, c->stream, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut,
+                      static_cast<const uint64_t*>( nullptr ) );
+        TIMED_LAUNCH( c, 0, c->stream, 9, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc,
+                      static_cast<const uint64_t*>( nullptr ) );
+        HIP_TRY( c, hipEventRecord( c->evStep[2], c->stream ) );
+        HIP_TRY( c, hipGetLastError() );
+        HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
+        HIP_TRY( c, hipStreamSynchronize( c->stream ) );
     }
-    rc = ensureOutput( c, total );
-    if ( rc != MI355X_BZ2_OK ) return rc;
-    HIP_TRY( c, hipMemcpyAsync( c->dMeta, c->hMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) );
-    TIMED_LAUNCH( c, 0, c->stream, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut );
-    TIMED_LAUNCH( c, 0, c->stream, 9, k_crc, dim3( n ), dim3( CRC_THREADS ), 0, c->stream, c->dMeta, c->dOut, c->crc );
-    HIP_TRY( c, hipEventRecord( c->evStep[2], c->stream ) );
-    HIP_TRY( c, hipGetLastError() );
-    HIP_TRY( c, hipMemcpyAsync( c->hMeta, c->dMeta, (size_t)n * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) );
-    HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    c->outSizeHint = std::max( c->outSizeHint, total );
 
     for ( uint32_t i = 0; i < n; ++i ) {
         const BlockMeta& m = c->hMeta[c->hSlotOf[i]];
@@ -1260,16 +1335,14 @@ mi355x_bz2_find_magic_device( mi355x_bz2_ctx* c, uint64_t magic48, uint64_t* bit
         if ( c->inSize < 6 ) return MI355X_BZ2_OK;
         HIP_TRY( c, hipSetDevice( c->device ) );
         if ( c->scanStream == nullptr ) HIP_TRY( c, hipStreamCreateWithFlags( &c->scanStream, hipStreamNonBlocking ) );
-        if ( c->scanOrder == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &c->scanOrder, hipEventDisableTiming ) );
         if ( c->dScanFound == nullptr ) HIP_TRY( c, hipMalloc( &c->dScanFound, (size_t)CAP * sizeof( uint64_t ) ) );
         if ( c->dScanCounter == nullptr ) HIP_TRY( c, hipMalloc( &c->dScanCounter, sizeof( uint32_t ) ) );
         upload = c->upload;
         inBase = c->dIn;
         inSize = c->inSize;
-        if ( !upload ) {
-            /* a copy queued by set_input_host_async is on the context's stream */
-            HIP_TRY( c, hipEventRecord( c->scanOrder, c->stream ) );
-            HIP_TRY( c, hipStreamWaitEvent( c->scanStream, c->scanOrder, 0 ) );
+        if ( !upload && c->inReady != nullptr ) {
+            /* a copy queued by set_input_host_async is on the input stream */
+            HIP_TRY( c, hipStreamWaitEvent( c->scanStream, c->inReady, 0 ) );
         }
     }
     const auto fail = [c] ( const char* what ) {

@@ -397,11 +397,53 @@ rle_step( uint32_t k, bool eq )
     return eq ? ( k == 4 ? 0u : k + 1 ) : ( k == 4 ? 0u : 1u );
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * k_offsets: where every block's bytes go in the ragged output -- the exclusive prefix sum of the decoded sizes IN
+ * THE CALLER'S ORDER (slot_of[i] = slot of the i-th requested block).  On the device, so that the expansion and the CRC
+ * can be queued behind the walk without a round trip to the host.  result[0] = total bytes, result[1] = 1 if they do
+ * not fit into `capacity` (k_rle<true> and k_crc then do nothing and the host takes over with a larger buffer).
+ * ------------------------------------------------------------------------------------------------------------- */
+constexpr uint32_t OFFSETS_THREADS = 1024;
+
+__global__ __launch_bounds__( OFFSETS_THREADS ) void
+k_offsets( BlockMeta* meta, const uint32_t* __restrict__ slot_of, uint32_t n, uint64_t capacity, uint64_t* result )
+{
+    __shared__ uint64_t partial[OFFSETS_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = ( n + OFFSETS_THREADS - 1 ) / OFFSETS_THREADS;
+    const uint32_t lo = t * per < n ? t * per : n;
+    const uint32_t hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for ( uint32_t i = lo; i < hi; ++i ) {
+        const BlockMeta& m = meta[slot_of[i]];
+        sum += m.walk_ok ? m.decoded_size : 0;
+    }
+    partial[t] = sum;
+    __syncthreads();
+    for ( uint32_t step = 1; step < OFFSETS_THREADS; step *= 2 ) {
+        const uint64_t add = t >= step ? partial[t - step] : 0;
+        __syncthreads();
+        partial[t] += add;
+        __syncthreads();
+    }
+    uint64_t off = partial[t] - sum;     /* exclusive */
+    for ( uint32_t i = lo; i < hi; ++i ) {
+        BlockMeta& m = meta[slot_of[i]];
+        m.out_off = off;
+        off += m.walk_ok ? m.decoded_size : 0;
+    }
+    if ( t == OFFSETS_THREADS - 1 ) {
+        result[0] = partial[t];
+        result[1] = partial[t] + 256 > capacity ? 1 : 0;
+    }
+}
+
 template<bool WRITE>
 __global__ __launch_bounds__( RLE_THREADS ) void
 k_rle( BlockMeta*                   meta,
        const uint8_t* __restrict__  r_buf,
-       uint8_t* __restrict__        out )
+       uint8_t* __restrict__        out,
+       const uint64_t*              skip = nullptr )   /* non-zero: the output does not fit (k_offsets), nothing is written */
 {
     __shared__ uint32_t wfn[RLE_THREADS / 64];
     __shared__ uint64_t wsum[RLE_THREADS / 64];
@@ -416,6 +458,7 @@ k_rle( BlockMeta*                   meta,
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok ) return;
+    if ( WRITE && skip != nullptr && *skip != 0 ) return;
     if ( threadIdx.x < 256 ) {
         const uint32_t e = threadIdx.x;
         uint32_t t[5] = { 0, 1, 2, 3, 4 };
@@ -644,13 +687,15 @@ gf_pow8( const uint32_t* table, uint64_t nbytes )
 __global__ __launch_bounds__( CRC_THREADS ) void
 k_crc( BlockMeta*                  meta,
        const uint8_t* __restrict__ out,
-       CrcConsts                   cc )
+       CrcConsts                   cc,
+       const uint64_t*             skip = nullptr )
 {
     __shared__ uint32_t table[256];
     __shared__ uint32_t wcrc[CRC_THREADS / 64];
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok ) return;
+    if ( skip != nullptr && *skip != 0 ) return;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
         uint32_t c = tid << 24;

@@ -1,7 +1,7 @@
 """Developer probe: what ran when.  Reads a rocprofv3 --kernel-trace CSV (kernel_trace.csv) and prints, for the last
 `window` ms of the run: how many kernels were running at once (time share), time per kernel name (sum of durations, mean,
 count), the idle time, and a coarse text timeline per queue.
-Usage: python tools/timeline.py <kernel_trace.csv> [window_ms=200] [columns=160]"""
+Usage: python tools/timeline.py <kernel_trace.csv> [window_ms=200] [columns=160] [end_before_last_ms=0]"""
 import collections
 import csv
 import sys
@@ -16,14 +16,15 @@ def main():
     path = sys.argv[1]
     window_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 200.0
     columns = int(sys.argv[3]) if len(sys.argv) > 3 else 160
+    back_ms = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "0"),
                      int(r.get("Grid_Size", 0) or 0)))
     rows.sort()
-    t_end = max(r[1] for r in rows)
+    t_end = max(r[1] for r in rows) - int(back_ms * 1e6)
     t0 = t_end - int(window_ms * 1e6)
-    rows = [r for r in rows if r[1] > t0]
+    rows = [(s, min(e, t_end), n, q, g) for s, e, n, q, g in rows if e > t0 and s < t_end]
     # concurrency histogram
     events = []
     for s, e, *_ in rows:
