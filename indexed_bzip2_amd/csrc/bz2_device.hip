@@ -145,6 +145,7 @@ struct mi355x_bz2_ctx
     uint32_t* hSlotOf{ nullptr };     /* pinned: original index -> slot */
     uint32_t* dSlotOf{ nullptr };
     uint64_t* dTotals{ nullptr };     /* k_offsets: {total decoded bytes, does not fit} */
+    uint32_t* dScanQueue{ nullptr };  /* [MAX_GROUPS]: block counters of k_hscan<1> launched with a capped grid */
     uint64_t* hTotals{ nullptr };     /* pinned */
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
@@ -276,7 +277,7 @@ freeScratch( mi355x_bz2_ctx* c, bool now = true )
     c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegOff = nullptr; c->dSegCont = nullptr;
     c->dChain = nullptr; c->dStash = nullptr; c->dPlan = nullptr; c->dWalkBlk = nullptr; c->dWalkPre = nullptr;
     c->hOrder = nullptr; c->hSlotOf = nullptr; c->hMeta = nullptr; c->hOffsets = nullptr;
-    c->dSlotOf = nullptr; c->dTotals = nullptr; c->hTotals = nullptr;
+    c->dSlotOf = nullptr; c->dTotals = nullptr; c->hTotals = nullptr; c->dScanQueue = nullptr;
     c->capacity = 0;
 }
 
@@ -323,6 +324,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t oWalkPre = reserve( deviceBytes, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) );
     const size_t oSlotOf = reserve( deviceBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t oTotals = reserve( deviceBytes, 2 * sizeof( uint64_t ) );
+    const size_t oScanQueue = reserve( deviceBytes, MAX_GROUPS * sizeof( uint32_t ) );
     const size_t hOrderAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t hSlotOfAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t hMetaAt = reserve( hostBytes, (size_t)cap * sizeof( BlockMeta ) );
@@ -362,6 +364,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dWalkPre = reinterpret_cast<uint32_t*>( d + oWalkPre );
     c->dSlotOf = reinterpret_cast<uint32_t*>( d + oSlotOf );
     c->dTotals = reinterpret_cast<uint64_t*>( d + oTotals );
+    c->dScanQueue = reinterpret_cast<uint32_t*>( d + oScanQueue );
     c->hOrder = reinterpret_cast<uint32_t*>( h + hOrderAt );
     c->hSlotOf = reinterpret_cast<uint32_t*>( h + hSlotOfAt );
     c->hMeta = reinterpret_cast<BlockMeta*>( h + hMetaAt );
@@ -1015,6 +1018,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     /* 0: the waves of a block share the rows of one build (k_hscan<4 / 8>) instead of taking one group each (k_hscan_spec) */
     const char* ssp = std::getenv( "MI355X_BZ2_SCAN_SPEC" );
     const bool scanSpec = !( ssp != nullptr && ssp[0] == '0' );
+    /* most workgroups of a k_hscan<1> launch (0: one per block).  Ten of them fill the LDS of a CU for as long as
+     * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
+    const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
+    const uint32_t scanGrid = sg != nullptr ? (uint32_t)std::atoi( sg ) : 0u;
     const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
     const uint32_t scanTune = st != nullptr ? (uint32_t)std::atoi( st ) : 0u;
     const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
@@ -1063,20 +1070,24 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             } else if ( scanWaves >= 8 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             } else if ( scanWaves >= 4 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             } else if ( scanWaves >= 2 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             } else if ( scanPc ) {
                 /* one block per workgroup, producer + consumer wave (k_hscan_pc) */
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_pc, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order );
+            } else if ( scanGrid != 0 && scanGrid < m ) {
+                HIP_TRY( c, hipMemsetAsync( c->dScanQueue + g, 0, sizeof( uint32_t ), q ) );
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( scanGrid ), dim3( 64 ), 0, q, inWords, inSize, c->dOffsets + first,
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, c->dScanQueue + g );
             } else {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( m ), dim3( 64 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
+                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             }
             TIMED_LAUNCH( c, g, q, 13, k_hsym, dim3( ( MAX_SCAN_GROUPS + SYM_THREADS - 1 ) / SYM_THREADS, m ), dim3( SYM_THREADS ),
                           0, q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym );

@@ -40,7 +40,7 @@ constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SCAN_GROUPS = 18002;     /* 900 100 symbols: more than any block that k_mtf accepts */
 constexpr uint32_t GPOS_STRIDE = 18048;         /* u32 per block */
 constexpr uint32_t LEN_STOP = 0x80u;            /* length-table flag: the code is the end-of-block symbol */
-constexpr uint32_t SYM_THREADS = 256;           /* groups per k_hsym workgroup */
+constexpr uint32_t SYM_THREADS = 128;           /* groups per k_hsym workgroup */
 
 /** Decode tables of one block, written by k_hscan and read by every k_hsym workgroup of the block. */
 struct alignas( 16 ) HuffTables
@@ -591,10 +591,18 @@ k_hscan( const uint32_t* __restrict__ in_words,
          uint32_t* __restrict__       gpos_buf,
          uint32_t                     n_blocks,
          const uint32_t* __restrict__ order,
-         uint32_t                     tune )   /* debugging: 1 = one group per build, 2 = always the full span */
+         uint32_t                     tune,    /* debugging: 1 = one group per build, 2 = always the full span */
+         uint32_t*                    queue )  /* K == 1 only: not null = the workgroups take blocks from this counter (zeroed by
+                                                  the host) until none is left, so that a grid smaller than the batch -- one
+                                                  that leaves LDS to the kernels of other streams -- still decodes all of it */
 {
     __shared__ ScanShared<K> sh;
-    const uint32_t slotIndex = blockIdx.x;
+    for ( uint32_t slotIndex = blockIdx.x;; slotIndex += gridDim.x ) {
+    if ( K == 1 && queue != nullptr ) {
+        uint32_t taken = 0;
+        if ( threadIdx.x == 0 ) taken = atomicAdd( queue, 1u );
+        slotIndex = sfl( taken );
+    }
     if ( slotIndex >= n_blocks ) return;
     const uint32_t b = sfl( order[slotIndex] );
     const uint32_t lane = threadIdx.x & 63;
@@ -781,6 +789,8 @@ k_hscan( const uint32_t* __restrict__ in_words,
         sm.symbol_count = sh.hdr.symbol_count;
         sm.pad[0] = sm.pad[1] = 0;
         smeta[b] = sm;
+    }
+    if ( K != 1 || queue == nullptr ) return;
     }
 }
 

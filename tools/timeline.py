@@ -1,7 +1,7 @@
 """Developer probe: what ran when.  Reads a rocprofv3 --kernel-trace CSV (kernel_trace.csv) and prints, for the last
 `window` ms of the run: how many kernels were running at once (time share), time per kernel name (sum of durations, mean,
 count), the idle time, and a coarse text timeline per queue.
-Usage: python tools/timeline.py <kernel_trace.csv> [window_ms=200] [columns=160] [end_before_last_ms=0]"""
+Usage: python tools/timeline.py <kernel_trace.csv> [window_ms=200] [columns=160] [end_before_last_ms=0 | -1 = around the median kernel start]"""
 import collections
 import csv
 import sys
@@ -22,7 +22,11 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "0"),
                      int(r.get("Grid_Size", 0) or 0)))
     rows.sort()
-    t_end = max(r[1] for r in rows) - int(back_ms * 1e6)
+    if back_ms < 0:      # the window around the median kernel start: the middle of the run
+        starts = sorted(r[0] for r in rows)
+        t_end = starts[len(starts) // 2] + int(window_ms * 1e6 / 2)
+    else:
+        t_end = max(r[1] for r in rows) - int(back_ms * 1e6)
     t0 = t_end - int(window_ms * 1e6)
     rows = [(s, min(e, t_end), n, q, g) for s, e, n, q, g in rows if e > t0 and s < t_end]
     # concurrency histogram
