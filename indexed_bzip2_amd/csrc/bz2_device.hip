@@ -81,6 +81,9 @@ struct mi355x_bz2_ctx
     uint32_t flags{ 0 };
     hipStream_t stream{ nullptr };
     hipStream_t gstream[MAX_GROUPS]{};   /* gstream[0] == stream; higher groups = more expensive blocks, higher priority */
+    /* small batches: the two k_mtf instances of a group (each block belongs to one of them) side by side, see begin */
+    hipStream_t sideStream[MAX_GROUPS]{};
+    hipEvent_t evFork[MAX_GROUPS]{}, evJoin[MAX_GROUPS]{};
     std::string lastError;
     std::mutex mutex;
 
@@ -600,6 +603,14 @@ mi355x_bz2_destroy( mi355x_bz2_ctx* c )
     for ( int g = 1; g < MAX_GROUPS; ++g ) {
         if ( c->gstream[g] ) (void)hipStreamDestroy( c->gstream[g] );
     }
+    for ( int g = 0; g < MAX_GROUPS; ++g ) {
+        if ( c->sideStream[g] ) {
+            (void)hipStreamSynchronize( c->sideStream[g] );
+            (void)hipStreamDestroy( c->sideStream[g] );
+        }
+        if ( c->evFork[g] ) (void)hipEventDestroy( c->evFork[g] );
+        if ( c->evJoin[g] ) (void)hipEventDestroy( c->evJoin[g] );
+    }
     for ( auto& e : c->evGroupDone ) {
         if ( e ) (void)hipEventDestroy( e );
     }
@@ -1097,8 +1108,25 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                           reinterpret_cast<const uint32_t*>( inBase ), inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
                           m, order );
         }
-        TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
-        TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+        /* Every block belongs to one of the two k_mtf instances (by its symbol count), the other returns at once.  In a
+         * small batch each lasts as long as its slowest block (4 and 7 ms): side by side instead of one behind the other. */
+        if ( n <= 1280 ) {
+            if ( c->sideStream[g] == nullptr ) {
+                HIP_TRY( c, hipStreamCreateWithFlags( &c->sideStream[g], hipStreamNonBlocking ) );
+                HIP_TRY( c, hipEventCreateWithFlags( &c->evFork[g], hipEventDisableTiming ) );
+                HIP_TRY( c, hipEventCreateWithFlags( &c->evJoin[g], hipEventDisableTiming ) );
+            }
+            hipStream_t side = c->sideStream[g];
+            HIP_TRY( c, hipEventRecord( c->evFork[g], q ) );
+            HIP_TRY( c, hipStreamWaitEvent( side, c->evFork[g], 0 ) );
+            TIMED_LAUNCH( c, g, side, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+            HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
+            TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+            HIP_TRY( c, hipStreamWaitEvent( q, c->evJoin[g], 0 ) );
+        } else {
+            TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+            TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+        }
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
         TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
