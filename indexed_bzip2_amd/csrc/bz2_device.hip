@@ -1033,6 +1033,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
     const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
     const uint32_t scanGrid = sg != nullptr ? (uint32_t)std::atoi( sg ) : 0u;
+    const char* mn = std::getenv( "MI355X_BZ2_MTF_NARROW" );   /* 1: 256 lanes per block in k_mtf whatever the batch size */
+    const bool mtfNarrow = mn != nullptr && mn[0] == '1';
     const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
     const uint32_t scanTune = st != nullptr ? (uint32_t)std::atoi( st ) : 0u;
     const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
@@ -1119,9 +1121,16 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             hipStream_t side = c->sideStream[g];
             HIP_TRY( c, hipEventRecord( c->evFork[g], q ) );
             HIP_TRY( c, hipStreamWaitEvent( side, c->evFork[g], 0 ) );
-            TIMED_LAUNCH( c, g, side, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
-            HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
-            TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+            if ( n <= 256 && !mtfNarrow ) {
+                /* few blocks: 512 lanes per block, each with half the symbols */
+                TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
+                TIMED_LAUNCH( c, g, q, 1, ( k_mtf<MTF_LANE_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+            } else {
+                TIMED_LAUNCH( c, g, side, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
+                TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+            }
             HIP_TRY( c, hipStreamWaitEvent( q, c->evJoin[g], 0 ) );
         } else {
             TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );

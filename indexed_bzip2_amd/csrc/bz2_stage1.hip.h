@@ -857,13 +857,15 @@ struct ByteSink
     }
 };
 
-/** LANE_STRIDE = bytes between the lists of consecutive lanes = list capacity + 16.  Two instances: 272 (any block) and
+/** THREADS = lanes = chunks of the symbol stream: 256, or 512 for small batches, whose blocks should be through quickly (a
+ * lane's two passes are half as long; 139 / 74 KB of LDS: one or two blocks per CU).
+ * LANE_STRIDE = bytes between the lists of consecutive lanes = list capacity + 16.  Two instances: 272 (any block) and
  * MTF_SMALL_STRIDE (blocks that use at most MTF_SMALL_STRIDE - 16 symbols: text), whose 37 KB of LDS let four
  * workgroups share a CU instead of two -- the kernel is bound by instruction issue at two waves per SIMD.  Both are
  * launched over all blocks, a workgroup whose block belongs to the other instance returns at once.  Both strides keep
  * the 16-byte accesses of 16 lanes on 64 distinct banks (stride / 4 mod 64 is an odd multiple of 4). */
-template<uint32_t LANE_STRIDE>
-__global__ __launch_bounds__( MTF_THREADS ) void
+template<uint32_t LANE_STRIDE, uint32_t THREADS = MTF_THREADS>
+__global__ __launch_bounds__( THREADS ) void
 k_mtf( BlockMeta* __restrict__       meta,
        const HuffMeta* __restrict__  hmeta,
        const uint16_t* __restrict__  sym_buf,
@@ -873,11 +875,11 @@ k_mtf( BlockMeta* __restrict__       meta,
        const uint32_t* __restrict__  order )
 {
     constexpr uint32_t LIST_ENTRIES = LANE_STRIDE - 16;
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[MTF_THREADS * LANE_STRIDE];   /* 68 / 36 KiB */
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[THREADS * LANE_STRIDE];   /* 68 / 36 KiB with 256 lanes */
     __shared__ uint4 permRows[16];
     __shared__ uint8_t cur[256];
-    __shared__ uint32_t starts[MTF_THREADS + 1];
-    __shared__ unsigned long long waveTotals[MTF_THREADS / 64];
+    __shared__ uint32_t starts[THREADS + 1];
+    __shared__ unsigned long long waveTotals[THREADS / 64];
     __shared__ uint32_t firstError;
 
     const uint32_t slot = blockIdx.x;
@@ -893,12 +895,12 @@ k_mtf( BlockMeta* __restrict__       meta,
     uint4* const mine = reinterpret_cast<uint4*>( listBytes + t * LANE_STRIDE );
 
     /* chunk boundaries: never inside a RUNA/RUNB digit sequence */
-    const uint32_t S = ( n + MTF_THREADS - 1 ) / MTF_THREADS;
+    const uint32_t S = ( n + THREADS - 1 ) / THREADS;
     uint32_t begin = t * S < n ? t * S : n;
     while ( begin < n && begin > 0 && sym[begin] <= 1 && sym[begin - 1] <= 1 ) ++begin;
     starts[t] = begin;
-    if ( t == 0 ) { starts[MTF_THREADS] = n; firstError = 0xFFFFFFFFu; }
-    cur[t] = stb_buf[(size_t)b * 256 + t];
+    if ( t == 0 ) { starts[THREADS] = n; firstError = 0xFFFFFFFFu; }
+    if ( t < 256 ) cur[t] = stb_buf[(size_t)b * 256 + t];
     if ( t < 16 ) permRows[t] = mtf_perm_row( t );
     for ( uint32_t k = 0; k < LIST_ENTRIES / 16; ++k ) {
         const uint32_t e = 16 * k;
@@ -937,18 +939,18 @@ k_mtf( BlockMeta* __restrict__       meta,
     if ( lane == 63 ) waveTotals[wave] = incl;
     __syncthreads();
     unsigned long long prefix = incl - count, total = 0;
-    for ( uint32_t w = 0; w < MTF_THREADS / 64; ++w ) {
+    for ( uint32_t w = 0; w < THREADS / 64; ++w ) {
         if ( w < wave ) prefix += waveTotals[w];
         total += waveTotals[w];
     }
 
     /* ---- compose the chunk permutations in order: lane c's list becomes the list valid at the start of chunk c ---- */
-    for ( uint32_t c = 0; c < MTF_THREADS; ++c ) {
+    for ( uint32_t c = 0; c < THREADS; ++c ) {
         /* entries beyond the list capacity are never moved (symbols that do not occur): thread t has nothing to do */
         uint8_t* const slotC = listBytes + c * LANE_STRIDE;
         const bool mineToDo = t < LIST_ENTRIES;
         const uint8_t v = mineToDo ? cur[slotC[t]] : 0;   /* entry t after chunk c = old entry at the permuted position */
-        const uint8_t o = cur[t];
+        const uint8_t o = mineToDo ? cur[t] : 0;
         __syncthreads();
         if ( mineToDo ) {
             slotC[t] = o;
