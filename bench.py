@@ -285,6 +285,7 @@ def main():
         gpu_ms = 0.0
         depth = len(decs)
         prefetch = os.environ.get("BENCH_NO_PREFETCH") != "1"     # development: copy and batch of a step strictly in turn
+        stagger = float(os.environ.get("BENCH_STAGGER_MS", "0")) / 1e3   # development: pause between the first launches
         for k in range(count + depth):
             if k >= depth:                       # step k - depth holds the context that step k needs
                 finish(k - depth)
@@ -294,6 +295,8 @@ def main():
                 if not resident and (k < depth or not prefetch):
                     d.set_input_host_async(host_ptr, my_bytes, keepalive=host_in)
                 d.begin_batch(offs_c, n_blocks)
+                if stagger and k + 1 < depth:
+                    time.sleep(stagger)
                 if not resident and prefetch and k + depth < count:
                     # the bytes of this context's NEXT step (step k + depth): their copy runs beside the kernels of this one
                     d.set_input_host_async(host_ptr, my_bytes, keepalive=host_in)

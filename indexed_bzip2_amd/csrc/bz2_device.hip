@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <algorithm>
@@ -418,6 +419,21 @@ static_assert( N_KERNELS <= MI355X_BZ2_MAX_KERNELS );
 }  // namespace
 
 /* record an event pair around one launch so that every kernel gets its own device duration */
+/* ONE k_walk at a time per process, whatever stream and context it comes from: every walk is ordered behind the one
+ * launched before it (MI355X_BZ2_WALK_SERIAL=0 turns this off).  A walk keeps one or two 3.6 MB tables per XCD in its
+ * 4 MB L2; walks of several block groups and contexts side by side push each other's tables out.  In turn, and with
+ * fewer workgroups each (64 per XCD instead of 256: the other kernels of the crowd fill the wave slots while the walk
+ * waits for its gathers), a step of the four-context bench takes 67.5 instead of 74 ms. */
+struct WalkChain
+{
+    std::mutex mutex;
+    hipEvent_t events[64]{};
+    uint32_t next{ 0 };
+    hipEvent_t last{ nullptr };
+    std::atomic<int> liveContexts{ 0 };
+};
+WalkChain g_walkChain;
+
 #define TIMED_LAUNCH( ctx, group, queue, index, ... )                                      \
     do {                                                                                   \
         ( ctx )->launched[group] |= 1u << ( index );                                       \
@@ -511,6 +527,7 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
         return MI355X_BZ2_ERR_NO_DEVICE;   /* kernels are built for gfx950 only */
     }
     auto* c = new mi355x_bz2_ctx();
+    g_walkChain.liveContexts.fetch_add( 1 );
     c->device = device;
     c->flags = config != nullptr ? config->flags : 0;
     if ( hipSetDevice( device ) != hipSuccess
@@ -567,6 +584,7 @@ void
 mi355x_bz2_destroy( mi355x_bz2_ctx* c )
 {
     if ( c == nullptr ) return;
+    g_walkChain.liveContexts.fetch_sub( 1 );
     (void)hipSetDevice( c->device );
     if ( c->stream ) (void)hipStreamSynchronize( c->stream );
     for ( int g = 1; g < MAX_GROUPS; ++g ) {
@@ -1009,7 +1027,11 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     }
 
     const char* wg = std::getenv( "MI355X_BZ2_WALK_WGS" );   /* tuning knob: workgroups per XCD */
-    const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0 ? (uint32_t)std::atoi( wg ) : WALK_WGS_PER_XCD;
+    /* measured, walks in turn: four contexts in flight 64 workgroups 67.4 ms per step, 128: 68.6, 256: 72.8; a single context
+     * 64: 85.6 ms per batch, 128: 81.0, 256 (walks of the block groups side by side): 84.0 */
+    const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0
+                               ? (uint32_t)std::atoi( wg )
+                               : ( g_walkChain.liveContexts.load() >= 3 ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
     const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
 
@@ -1033,6 +1055,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
     const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
     const uint32_t scanGrid = sg != nullptr ? (uint32_t)std::atoi( sg ) : 0u;
+    const char* wsr = std::getenv( "MI355X_BZ2_WALK_SERIAL" );
+    const bool walkSerial = !( wsr != nullptr && wsr[0] == '0' );
     const char* mn = std::getenv( "MI355X_BZ2_MTF_NARROW" );   /* 1: 256 lanes per block in k_mtf whatever the batch size */
     const bool mtfNarrow = mn != nullptr && mn[0] == '1';
     const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
@@ -1138,8 +1162,19 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         }
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
-        TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
-                      meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+        if ( walkSerial ) {
+            const std::scoped_lock chain( g_walkChain.mutex );
+            if ( g_walkChain.last != nullptr ) HIP_TRY( c, hipStreamWaitEvent( q, g_walkChain.last, 0 ) );
+            TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
+                          meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            hipEvent_t& slot = g_walkChain.events[g_walkChain.next++ % 64];
+            if ( slot == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &slot, hipEventDisableTiming ) );
+            HIP_TRY( c, hipEventRecord( slot, q ) );
+            g_walkChain.last = slot;
+        } else {
+            TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
+                          meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+        }
         TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segCont, segOff, chain );
         TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
                       meta, tab, chain, stash, rbuf );

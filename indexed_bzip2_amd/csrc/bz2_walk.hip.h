@@ -5,8 +5,9 @@
  * (FETCH_SIZE 127 GB per pass for 9 GB of tables): ~60 blocks' tables (230 MB) were in flight at once, so nothing
  * stayed in an XCD's 4 MiB L2.  Here every block is assigned to ONE XCD queue (block i -> queue i mod 8), each
  * workgroup reads its XCC id (s_getreg HW_REG_XCC_ID) and pulls chunks of consecutive segments from its own XCD's
- * queue, so an XCD works on two or three 3.6 MB tables at a time (WALK_WGS_PER_XCD = 256 workgroups of 256 lanes = all
- * wave slots: measured best; 48 workgroups kept one table per L2 but hid too little latency).  The gathers still miss
+ * queue, so an XCD works on one or two 3.6 MB tables at a time.  Workgroups per XCD: 256 (all wave slots) are best for a
+ * walk that has the GPU to itself, but it never has: with the walks of all groups and contexts taking turns (bz2_device.hip)
+ * and the other kernels filling the wave slots, 128 (64 with three or more contexts in flight) give the shortest steps.  The gathers still miss
  * L2 mostly (35 B of fabric traffic per step, PMC) but are served by the 256 MB MALL rather than HBM.  Lanes refill
  * from the chunk through an LDS counter, so a short segment does not idle its lane.  A workgroup whose queue is
  * exhausted helps the other queues; nobody ever waits on another workgroup, every loop is bounded by atomic counters
@@ -25,7 +26,8 @@ namespace bz2gpu
 {
 constexpr uint32_t WALK_THREADS = 256;
 constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
-constexpr uint32_t WALK_WGS_PER_XCD = 256;
+constexpr uint32_t WALK_WGS_PER_XCD = 128;    /* one or two contexts */
+constexpr uint32_t WALK_WGS_CROWD = 64;       /* three or more contexts alive: see bz2_device.hip */
 constexpr uint32_t WALK_QUEUES = 8;
 constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps (two 64-B lines per segment: 1 % of the
                                                 bytes lie beyond, 10 % with one line) */
