@@ -229,10 +229,11 @@ class Decoder:
         self._check(lib().mi355x_bz2_set_input_host(self._h, data, len(data)))
 
     def set_input_host_async(self, ptr: int, size: int, keepalive=None):
-        """Queue the H2D copy of `size` bytes at host address `ptr` (page-locked memory) on the decoder's stream and
-        return: the next begin_batch / decode_batch is ordered behind it.  The memory must stay valid until that batch
-        has ended."""
-        self._input_ref = keepalive
+        """Queue the H2D copy of `size` bytes at host address `ptr` (page-locked memory) on the decoder's input stream
+        and return: the next begin_batch / decode_batch is ordered behind it.  May be called while a batch is in flight
+        (the bytes of the next one).  The memory must stay valid until the batch that uses it has ended."""
+        # the previous input may still be on its way to the GPU or in use by the batch in flight: keep it too
+        self._input_ref = (getattr(self, "_input_ref", None), keepalive)
         self._check(lib().mi355x_bz2_set_input_host_async(self._h, ptr, size))
 
     def set_input_device(self, ptr: int, size: int, keepalive=None):

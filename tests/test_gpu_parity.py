@@ -230,6 +230,32 @@ def test_background_copy_overlaps_the_next_batch(native, oracle):
     d.close()
 
 
+def test_next_input_is_copied_while_a_batch_is_in_flight(native, oracle):
+    """mi355x_bz2_set_input_host_async during a batch (what bench.py does every step): the bytes of the NEXT batch go
+    into the context's second input buffer and leave the batch in flight alone; batches alternate between two different
+    files, of different sizes so that both buffers are allocated and one of them grows."""
+    import ctypes
+    raws = [datagen.text_like(1_500_000, 71) + datagen.random_bytes(300_000, 72), datagen.random_bytes(900_000, 73),
+            datagen.text_like(2_600_000, 74)]
+    encs = [datagen.compress(r, 9) for r in raws]
+    offs = [native.find_magic(e) for e in encs]
+    pinned = [(ctypes.c_ubyte * len(e)).from_buffer_copy(e) for e in encs]      # stays alive and in place
+    d = native.Decoder()
+    arrays = [d.make_arrays(o) for o in offs]
+    d.set_input_host_async(ctypes.addressof(pinned[0]), len(encs[0]), keepalive=pinned[0])
+    order = [0, 1, 2, 1, 0, 2, 2, 0]
+    for step, which in enumerate(order):
+        d.begin_batch(arrays[which][0], len(offs[which]))
+        if step + 1 < len(order):
+            nxt = order[step + 1]
+            d.set_input_host_async(ctypes.addressof(pinned[nxt]), len(encs[nxt]), keepalive=pinned[nxt])
+        total = d.end_batch(arrays[which][1])
+        assert total == len(raws[which]), (step, which)
+        assert all(arrays[which][1][k].status == 0 for k in range(len(offs[which]))), (step, which)
+        assert d.copy_output(0, total) == raws[which], (step, which)
+    d.close()
+
+
 def test_warmup(native):
     """mi355x_bz2_warmup: optional, idempotent, and says so if the device does not exist."""
     native.warmup(0, background=False)
@@ -410,13 +436,16 @@ def bench_slice(native):
     return _slice["v"]
 
 
-@pytest.mark.parametrize("variant", ["scan-pc", "scan-1", "scan-2", "scan-4", "scan-8", "spec-4", "spec-8", "window"])
+@pytest.mark.parametrize("variant", ["scan-pc", "scan-1", "scan-2", "scan-4", "scan-8", "spec-4", "spec-8", "window", "mtf-256"])
 def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
     """Every form of the Huffman stage -- k_hscan_pc, k_hscan with 1, 2, 4 or 8 wavefronts per block, k_hscan_spec with 4 or 8
     (+ k_hsym) and the single-chain k_huff -- against the oracle, whatever the batch size would select by itself: valid data of all kinds, streams no
     libbz2 writes, one invalid stream per reference throw site, and seeded damage (every field of every record)."""
     if variant == "window":
         monkeypatch.setenv("MI355X_BZ2_HUFF", "window")
+    elif variant == "mtf-256":
+        # the 256-lane k_mtf instances, which batches of more than 256 blocks use (small batches take the 512-lane ones)
+        monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     else:
         # scan-pc: producer + consumer wave per block (k_hscan_pc), scan-N: N cooperating waves (k_hscan<N>),
         # spec-N: N waves on N consecutive groups (k_hscan_spec<N>)
