@@ -148,7 +148,7 @@ def main():
         args.contexts = 4
     # every decoder context drives up to 4 HIP streams: without this the runtime maps them onto 4 hardware queues and
     # streams that share a queue serialize (must be set before the HIP runtime starts)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(24, 4 * args.contexts)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.contexts))
     import torch   # first: the process must use ONE HIP runtime (torch's), the extension binds to the loaded one
     import torch.distributed as dist
 

@@ -170,7 +170,7 @@ int mi355x_bz2_decode_batch( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offs
  * offsets, runs the expansion and the CRC and fills `results` (n entries as given to _begin).  One batch per context
  * can be in flight; two contexts used alternately (begin(A), begin(B), end(A), begin(A'), end(B), ...) overlap the
  * Huffman stage of one batch with the throughput kernels of the other.  Each context drives 4 HIP streams: with two
- * of them set GPU_MAX_HW_QUEUES=24 before the HIP runtime starts, or streams share hardware queues and serialize. */
+ * of them set GPU_MAX_HW_QUEUES=16 before the HIP runtime starts, or streams share hardware queues and serialize. */
 int mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offsets, uint32_t n_blocks );
 int mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* ctx, mi355x_bz2_block_result* results, uint64_t* total_decoded );
 

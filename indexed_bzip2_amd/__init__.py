@@ -8,10 +8,11 @@ __version__ = "0.1.0"
 import os as _os
 
 # the reader drives two or three decoder contexts with up to eight HIP streams each (block groups, input, copy-out): the
-# runtime's default of 4 hardware queues serialises them (measured: 8 queues 9.9 GB/s, 24 queues 11.1 GB/s for a cold 8 GiB
-# read; the bench at 8 queues 85.8 ms per step, at 16 or more 67).  The HIP runtime reads this when it starts, so it only
-# helps if nothing has touched the GPU yet; an existing setting wins
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# runtime's default of 4 hardware queues serialises them.  Measured: the bench (four contexts, 2 560 blocks per batch) 85.8 ms
+# per step with 8 queues, 67 with 16 or more; batches of 310 blocks on four contexts 12.4 ms per step with 16 queues but 17.3
+# with 24 or 32.  The HIP runtime reads this when it starts, so it only helps if nothing has touched the GPU yet; an
+# existing setting wins
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from ._native import Bz2Error, Decoder, find_magic, lib, status_string, warmup  # noqa: F401
 from .reader import (IndexedBzip2File, IndexedBzip2FileRaw, open, read_block_offsets,  # noqa: F401

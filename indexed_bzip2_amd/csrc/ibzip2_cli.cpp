@@ -353,7 +353,7 @@ main( int argc, char** argv )
 {
     /* the reader drives two decoder contexts with four HIP streams each: give every stream its own hardware queue
      * (read by the HIP runtime when it starts; an existing setting wins) */
-    ::setenv( "GPU_MAX_HW_QUEUES", "24", 0 );
+    ::setenv( "GPU_MAX_HW_QUEUES", "16", 0 );
     Options o;
     if ( parseArguments( argc, argv, o ) != 0 ) return 1;
 
