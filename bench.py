@@ -254,11 +254,12 @@ def main():
         if rank == 0:
             gather_buf = buf
         if args.backend == "nccl":
-            # the sends read the context's output buffer asynchronously: its next expansion must not start before
-            # they are done (checked in finish() before that context's next end_batch)
+            # the sends read the context's output buffer asynchronously: the context's next batch writes its output (queued
+            # by its begin_batch, long before its end_batch) only behind this event
             done = torch.cuda.Event()
             done.record()
             gather_done[id(decoder)] = done
+            decoder.hold_output_until(done.cuda_event, keepalive=done)
 
     offs_c, _ = dec.make_arrays(my_offsets)
     res_cs = [d.make_arrays(my_offsets)[1] for d in decs]

@@ -185,6 +185,11 @@ int mi355x_bz2_copy_output( mi355x_bz2_ctx* ctx, uint64_t offset, uint64_t size,
  * BlockFetcher.hpp:620-642).  `host_dst` should be page-locked and must stay valid until _end has returned.
  * mi355x_bz2_output_device keeps pointing at the batch finished last. */
 int mi355x_bz2_copy_output_begin( mi355x_bz2_ctx* ctx, uint64_t offset, uint64_t size, void* host_dst );
+/* For callers that read mi355x_bz2_output_device themselves, asynchronously (a collective that sends the decoded extent
+ * to another GPU): `hip_event` (a hipEvent_t recorded behind that read) is waited for by the context's stream before the
+ * NEXT batch writes its output -- not before its other kernels.  The event is not owned and must stay valid until the next
+ * decode_batch_end has returned.  Call between decode_batch_end and the next decode_batch_begin. */
+int mi355x_bz2_hold_output_until( mi355x_bz2_ctx* ctx, void* hip_event );
 int mi355x_bz2_copy_output_end( mi355x_bz2_ctx* ctx );
 int mi355x_bz2_last_timings( const mi355x_bz2_ctx* ctx, mi355x_bz2_timings* timings );
 /* Only the duration of the last batch's kernel pipeline (HIP events before the first and after the last kernel): one

@@ -104,6 +104,7 @@ SYMBOLS = [
     ("mi355x_bz2_copy_output", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     ("mi355x_bz2_copy_output_begin", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     ("mi355x_bz2_copy_output_end", ctypes.c_int, [_vp]),
+    ("mi355x_bz2_hold_output_until", ctypes.c_int, [_vp, _vp]),
     ("mi355x_bz2_last_timings", ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     ("mi355x_bz2_last_pipeline_ms", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     ("mi355x_bz2_kernel_name", ctypes.c_char_p, [ctypes.c_uint32]),
@@ -307,6 +308,12 @@ class Decoder:
 
     def stream_ptr(self) -> int:
         return lib().mi355x_bz2_stream(self._h) or 0
+
+    def hold_output_until(self, hip_event: int, keepalive=None):
+        """The next batch's output kernels wait for `hip_event` (e.g. torch.cuda.Event.cuda_event recorded behind a
+        collective that reads output_device_ptr()); the event object must stay alive: pass it as `keepalive`."""
+        self._output_hold = keepalive
+        self._check(lib().mi355x_bz2_hold_output_until(self._h, hip_event))
 
     def copy_output_begin(self, offset: int, size: int):
         """Background D2H of the last batch's bytes; returns the ctypes buffer, valid after copy_output_end()."""

@@ -170,6 +170,7 @@ struct mi355x_bz2_ctx
     hipStream_t copyStream{ nullptr };
     uint8_t* dOut{ nullptr };             /* == out[outCurrent].bytes */
     uint64_t outSizeHint{ 0 };            /* the largest batch output so far */
+    hipEvent_t outputHold{ nullptr };     /* mi355x_bz2_hold_output_until: not owned */
 
     /* mi355x_bz2_find_magic_device: a stream and buffers of its own, so that a scan neither queues behind a batch nor
      * stops one (hipFree waits for the whole device) */
@@ -1194,6 +1195,11 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * is chosen now, for the size that blocks of the usual compressors have at most (900 000 bytes each); if these
      * decode to more, k_offsets says so, the two kernels do nothing and decode_batch_end repeats them with a buffer of
      * the right size. */
+    if ( c->outputHold != nullptr ) {
+        /* somebody still reads the last batch's bytes on the device (mi355x_bz2_hold_output_until) */
+        HIP_TRY( c, hipStreamWaitEvent( c->stream, c->outputHold, 0 ) );
+        c->outputHold = nullptr;
+    }
     hipLaunchKernelGGL( k_offsets, dim3( 1 ), dim3( OFFSETS_THREADS ), 0, c->stream, c->dMeta, c->dSlotOf, n,
                         c->out[c->outCurrent].capacity, c->dTotals );
     TIMED_LAUNCH( c, 0, c->stream, 8, k_rle<true>, dim3( n ), dim3( RLE_THREADS ), 0, c->stream, c->dMeta, c->dR, c->dOut,
@@ -1320,6 +1326,19 @@ mi355x_bz2_copy_output( mi355x_bz2_ctx* c, uint64_t offset, uint64_t size, void*
     HIP_TRY( c, hipSetDevice( c->device ) );
     HIP_TRY( c, hipMemcpyAsync( hostDst, c->dOut + offset, size, hipMemcpyDeviceToHost, c->stream ) );
     HIP_TRY( c, hipStreamSynchronize( c->stream ) );
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_hold_output_until( mi355x_bz2_ctx* c, void* hipEvent )
+{
+    if ( c == nullptr ) return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    const std::scoped_lock lock( c->mutex );
+    if ( c->pendingBlocks != 0 ) {
+        c->lastError = "hold_output_until: a batch is in flight (its output kernels are queued already)";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    c->outputHold = static_cast<hipEvent_t>( hipEvent );
     return MI355X_BZ2_OK;
 }
 

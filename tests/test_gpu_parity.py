@@ -256,6 +256,35 @@ def test_next_input_is_copied_while_a_batch_is_in_flight(native, oracle):
     d.close()
 
 
+def test_hold_output_until_an_event(native, oracle):
+    """mi355x_bz2_hold_output_until (bench.py: an RCCL send reads the decoded extent on the device): the next batch's
+    output kernels are ordered behind the caller's event; results are unchanged, the call is refused while a batch is in
+    flight.  The event is a plain hipEvent_t made through the HIP runtime the library itself uses."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = datagen.text_like(1_400_000, 81) + datagen.random_bytes(400_000, 82)
+    enc = datagen.compress(raw, 9)
+    offs = native.find_magic(enc)
+    d = native.Decoder()
+    d.set_input(enc)
+    want, total = d.decode_batch(offs)
+    event = ctypes.c_void_p()
+    assert hip.hipEventCreate(ctypes.byref(event)) == 0
+    for _ in range(3):
+        assert hip.hipEventRecord(event, None) == 0          # "somebody has read the output" on the null stream
+        d.hold_output_until(event.value, keepalive=event)
+        got, total2 = d.decode_batch(offs)
+        assert (got, total2) == (want, total)
+        assert d.copy_output(0, total) == raw
+    arrays = d.make_arrays(offs)
+    d.begin_batch(arrays[0], len(offs))
+    with pytest.raises(native.Bz2Error):
+        d.hold_output_until(event.value)
+    d.end_batch(arrays[1])
+    d.close()
+    assert hip.hipEventDestroy(event) == 0
+
+
 def test_warmup(native):
     """mi355x_bz2_warmup: optional, idempotent, and says so if the device does not exist."""
     native.warmup(0, background=False)
