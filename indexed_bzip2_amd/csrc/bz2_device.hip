@@ -433,7 +433,8 @@ struct WalkChain
     hipEvent_t last{ nullptr };
     std::atomic<int> liveContexts{ 0 };
 };
-WalkChain g_walkChain;
+WalkChain g_walkChains[16];      /* by device: walks on different GPUs have nothing to do with each other */
+WalkChain& walkChainOf( int device ) { return g_walkChains[(unsigned)device % 16u]; }
 
 #define TIMED_LAUNCH( ctx, group, queue, index, ... )                                      \
     do {                                                                                   \
@@ -528,8 +529,8 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
         return MI355X_BZ2_ERR_NO_DEVICE;   /* kernels are built for gfx950 only */
     }
     auto* c = new mi355x_bz2_ctx();
-    g_walkChain.liveContexts.fetch_add( 1 );
     c->device = device;
+    walkChainOf( device ).liveContexts.fetch_add( 1 );
     c->flags = config != nullptr ? config->flags : 0;
     if ( hipSetDevice( device ) != hipSuccess
          || hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
@@ -585,7 +586,7 @@ void
 mi355x_bz2_destroy( mi355x_bz2_ctx* c )
 {
     if ( c == nullptr ) return;
-    g_walkChain.liveContexts.fetch_sub( 1 );
+    walkChainOf( c->device ).liveContexts.fetch_sub( 1 );
     (void)hipSetDevice( c->device );
     if ( c->stream ) (void)hipStreamSynchronize( c->stream );
     for ( int g = 1; g < MAX_GROUPS; ++g ) {
@@ -1032,7 +1033,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * 64: 85.6 ms per batch, 128: 81.0, 256 (walks of the block groups side by side): 84.0 */
     const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0
                                ? (uint32_t)std::atoi( wg )
-                               : ( g_walkChain.liveContexts.load() >= 3 ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
+                               : ( walkChainOf( c->device ).liveContexts.load() >= 3 ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
     const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
 
@@ -1164,14 +1165,15 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
         if ( walkSerial ) {
-            const std::scoped_lock chain( g_walkChain.mutex );
-            if ( g_walkChain.last != nullptr ) HIP_TRY( c, hipStreamWaitEvent( q, g_walkChain.last, 0 ) );
+            WalkChain& walks = walkChainOf( c->device );
+            const std::scoped_lock chain( walks.mutex );
+            if ( walks.last != nullptr ) HIP_TRY( c, hipStreamWaitEvent( q, walks.last, 0 ) );
             TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
                           meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
-            hipEvent_t& slot = g_walkChain.events[g_walkChain.next++ % 64];
+            hipEvent_t& slot = walks.events[walks.next++ % 64];
             if ( slot == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &slot, hipEventDisableTiming ) );
             HIP_TRY( c, hipEventRecord( slot, q ) );
-            g_walkChain.last = slot;
+            walks.last = slot;
         } else {
             TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
                           meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
