@@ -262,14 +262,21 @@ k_walk( const BlockMeta* __restrict__ meta,
                     for ( uint32_t quad = 0; quad < STASH_BYTES / 16; ++quad ) {
                         if ( !done ) {
                             uint32_t w[4] = { 0, 0, 0, 0 };
+                            /* four steps per look at `done`: a lane whose segment ends inside the four goes on in place
+                             * (it re-reads its last entry, adds nothing) instead of costing every step a change of the
+                             * execution mask */
 #pragma unroll
-                            for ( uint32_t i = 0; i < 16; ++i ) {
+                            for ( uint32_t i = 0; i < 16; i += 4 ) {
                                 if ( !done ) {
-                                    w[i >> 2] |= ( e & 0xFFu ) << ( 8 * ( i & 3u ) );
-                                    ++len;
-                                    p = ( e >> 8 ) & LF_MASK;
-                                    e = tab[p];
-                                    done = ( e & MARK ) || len >= N;
+#pragma unroll
+                                    for ( uint32_t k = i; k < i + 4; ++k ) {
+                                        const uint32_t live = done ? 0u : 1u;
+                                        w[k >> 2] |= done ? 0u : ( e & 0xFFu ) << ( 8 * ( k & 3u ) );
+                                        len += live;
+                                        p = done ? p : ( e >> 8 ) & LF_MASK;
+                                        e = tab[p];
+                                        done = ( e & MARK ) || len >= N;
+                                    }
                                 }
                             }
                             /* written once, read much later by k_emit: keep it out of the way of the table lines in L2 */
