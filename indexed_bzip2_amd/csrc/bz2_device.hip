@@ -1028,12 +1028,15 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         HIP_TRY( c, hipStreamWaitEvent( streamOf( g ), c->evStep[1], 0 ) );
     }
 
+    /* three or more contexts alive on this device: batches run side by side (a reader, the bench), kernels are chosen for
+     * the throughput of the crowd; one or two: for the latency of the batch */
+    const bool crowd = walkChainOf( c->device ).liveContexts.load() >= 3;
     const char* wg = std::getenv( "MI355X_BZ2_WALK_WGS" );   /* tuning knob: workgroups per XCD */
     /* measured, walks in turn: four contexts in flight 64 workgroups 67.4 ms per step, 128: 68.6, 256: 72.8; a single context
      * 64: 85.6 ms per batch, 128: 81.0, 256 (walks of the block groups side by side): 84.0 */
     const uint32_t wgsPerXcd = wg != nullptr && std::atoi( wg ) > 0
                                ? (uint32_t)std::atoi( wg )
-                               : ( walkChainOf( c->device ).liveContexts.load() >= 3 ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
+                               : ( crowd ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
     const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
 
@@ -1098,8 +1101,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
              * (k_hscan_spec, bz2_hscan.hip.h), when few blocks have to be through quickly (their LDS, one build per wave,
              * allows 4 and 2 blocks per CU).  Measured: sixteen waves gain nothing over eight (the chain from group to
              * group and the barriers grow with the waves); eight are faster than four for ONE batch of 320 blocks (15 vs
-             * 18 ms) but slower when four such batches run side by side (14.5 vs 13.4 ms per batch) */
-            const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves : ( n <= 128 ? 8u : ( n <= 1280 ? 4u : 1u ) );
+             * 18 ms) but slower when four such batches run side by side (14.5 vs 13.4 ms per batch): eight up to 384
+             * blocks for a caller with one or two contexts, up to 128 in a crowd */
+            const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves
+                                                            : ( n <= ( crowd ? 128u : 384u ) ? 8u : ( n <= 1280 ? 4u : 1u ) );
             const auto* const inWords = reinterpret_cast<const uint32_t*>( inBase );
             if ( scanWaves >= 8 && scanSpec ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
@@ -1147,7 +1152,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             hipStream_t side = c->sideStream[g];
             HIP_TRY( c, hipEventRecord( c->evFork[g], q ) );
             HIP_TRY( c, hipStreamWaitEvent( side, c->evFork[g], 0 ) );
-            if ( n <= 256 && !mtfNarrow ) {   /* (up to 640: one batch of 320 blocks 30.4 -> 28.0 ms, four side by side 11.9 -> 12.1) */
+            /* (up to 640 blocks: one batch of 320 blocks 30.4 -> 28.0 ms, but four side by side 11.9 -> 12.1 ms per batch) */
+            if ( n <= ( crowd ? 256u : 640u ) && !mtfNarrow ) {
                 /* few blocks: 512 lanes per block, each with half the symbols */
                 TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
                 HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
