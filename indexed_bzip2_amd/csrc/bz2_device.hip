@@ -1155,7 +1155,12 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             /* (up to 640 blocks: one batch of 320 blocks 30.4 -> 28.0 ms, but four side by side 11.9 -> 12.1 ms per batch) */
             if ( n <= ( crowd ? 256u : 640u ) && !mtfNarrow ) {
                 /* few blocks: 512 lanes per block, each with half the symbols */
-                TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                if ( n <= 64 ) {
+                    /* (the 128-entry lists of 1 024 lanes still fit the LDS of a CU: 152 KB) */
+                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 1024> ), dim3( m ), dim3( 1024 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                } else {
+                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                }
                 HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
                 TIMED_LAUNCH( c, g, q, 1, ( k_mtf<MTF_LANE_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
             } else {
