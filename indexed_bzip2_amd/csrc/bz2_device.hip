@@ -769,6 +769,15 @@ mi355x_bz2_set_input_host_streamed( mi355x_bz2_ctx* c, const uint8_t* bytes, uin
         buffer = {};
     }
     c->inPending = false;
+    {
+        /* the whole file becomes resident (bounded residency is not implemented): say so if it cannot */
+        size_t freeBytes = 0, totalBytes = 0;
+        if ( hipMemGetInfo( &freeBytes, &totalBytes ) == hipSuccess && (uint64_t)freeBytes < size + ( uint64_t( 1 ) << 30 ) ) {
+            c->lastError = "the compressed input (" + std::to_string( size >> 20 ) + " MiB) does not fit the free device memory ("
+                           + std::to_string( freeBytes >> 20 ) + " MiB): the reader keeps the whole file resident";
+            return MI355X_BZ2_ERR_DEVICE;
+        }
+    }
     auto upload = std::make_shared<InputUpload>();
     upload->total = size;
     upload->device = c->device;
