@@ -197,6 +197,10 @@ def find_magic(data: bytes, magic: int = MAGIC_BLOCK, threads: int = 0):
     return list(arr[:n])
 
 
+class _KeptInputs(tuple):
+    """(previous, current) host buffers of set_input_host_async."""
+
+
 class Decoder:
     """One decoder context = one GPU + one HIP stream (mi355x_bz2_ctx)."""
 
@@ -233,8 +237,11 @@ class Decoder:
         """Queue the H2D copy of `size` bytes at host address `ptr` (page-locked memory) on the decoder's input stream
         and return: the next begin_batch / decode_batch is ordered behind it.  May be called while a batch is in flight
         (the bytes of the next one).  The memory must stay valid until the batch that uses it has ended."""
-        # the previous input may still be on its way to the GPU or in use by the batch in flight: keep it too
-        self._input_ref = (getattr(self, "_input_ref", None), keepalive)
+        # the previous input may still be on its way to the GPU or in use by the batch in flight: keep it too, and no more
+        # (the context has two input buffers: the batch in flight's and the next one's)
+        previous = self._input_ref
+        self._input_ref = (previous[1] if isinstance(previous, _KeptInputs) else previous, keepalive)
+        self._input_ref = _KeptInputs(self._input_ref)
         self._check(lib().mi355x_bz2_set_input_host_async(self._h, ptr, size))
 
     def set_input_device(self, ptr: int, size: int, keepalive=None):

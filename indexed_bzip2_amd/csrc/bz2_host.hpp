@@ -18,10 +18,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
-#include <deque>
 #include <functional>
 #include <limits>
 #include <map>
@@ -29,6 +29,7 @@
 #include <mutex>
 #include <optional>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -471,16 +472,43 @@ private:
 };
 
 /* ------------------------------------------------------------------------------------------------ block finder */
+/**
+ * The list of data-block bit offsets of a file, numbered from 0, which fills while the file is being read.  Two sources
+ * feed it: a scan thread of its own (bz2_finder.cpp over chunks of the host bytes, only as far ahead as somebody asks),
+ * and whoever knows the whole list at once (an index given by the caller, the GPU's k_find_magic over the resident file,
+ * the reader when it finds trailing garbage).  What the reference splits into BlockFinder + StreamedResults
+ * (src/core/BlockFinder.hpp:36-219, src/core/StreamedResults.hpp:26-156) is ONE monitor here:
+ *
+ *   - every member is guarded by m_lock; a list that is `complete` never changes its source again (it can only be cut);
+ *   - the scan thread carries the `epoch` it was started in and appends only while that is still the current one: adopt()
+ *     and cut() advance the epoch INSIDE the critical section in which they replace the list, so nothing the thread found
+ *     before can land behind a list it does not belong to, and no thread is started for a complete list (round 2 stopped
+ *     the thread first and took the lock afterwards: a reader could restart the scan in between);
+ *   - threads are joined outside the lock (the thread needs the lock to leave).
+ */
 class BlockFinder
 {
 public:
-    enum class GetReturnCode { SUCCESS, TIMEOUT, FAILURE };
+    /** Who hands over a whole list: the caller's word (an imported index) always counts, a scanner's only while the list
+     * is still open -- an index imported meanwhile, or a cut behind trailing garbage, stays (ADVICE r02, bz2_reader.cpp:505). */
+    enum class Authority { CALLER, SCANNER };
 
-    BlockFinder( const uint8_t* bytes, uint64_t size, uint64_t magic48, size_t prefetchCount, unsigned scanThreads ) :
+    /** Answer to "where does block `number` start": the offset if the list has it; `listComplete` tells a missing block
+     * of a finished list ("there is no such block") from one the scan has not reached yet. */
+    struct Answer
+    {
+        std::optional<size_t> bits;
+        bool listComplete{ false };
+    };
+
+    static constexpr double DO_NOT_WAIT = 0;
+    static constexpr double UNTIL_KNOWN = std::numeric_limits<double>::infinity();
+
+    BlockFinder( const uint8_t* bytes, uint64_t size, uint64_t magic48, size_t lookAhead, unsigned scanThreads ) :
         m_bytes( bytes ),
         m_size( size ),
         m_magic( magic48 ),
-        m_prefetchCount( prefetchCount ),
+        m_lookAhead( lookAhead ),
         m_scanThreads( std::max( 1u, scanThreads ) )
     {}
 
@@ -489,27 +517,33 @@ public:
         stopThreads();
     }
 
+    /** Starts the scan thread unless the list is complete or a thread is at work. */
     void
     startThreads()
     {
-        const std::lock_guard<std::mutex> hold( m_threadLock );
-        if ( !m_thread.joinable() && !m_finalized ) {
-            m_cancel = false;
-            m_thread = std::thread( [this] () { finderMain(); } );
+        std::thread finished;
+        {
+            const std::lock_guard<std::mutex> hold( m_lock );
+            finished = ensureScanning();
+        }
+        if ( finished.joinable() ) {
+            finished.join();
         }
     }
 
+    /** Stops the scan where it is (a later at() resumes it there). */
     void
     stopThreads()
     {
+        std::thread scanner;
         {
             const std::lock_guard<std::mutex> hold( m_lock );
-            m_cancel = true;
+            m_pause = true;
+            scanner = std::move( m_thread );
             m_wake.notify_all();
         }
-        const std::lock_guard<std::mutex> hold( m_threadLock );
-        if ( m_thread.joinable() ) {
-            m_thread.join();
+        if ( scanner.joinable() ) {
+            scanner.join();
         }
     }
 
@@ -520,150 +554,205 @@ public:
         return m_offsets.size();
     }
 
-    /** BlockFinder::finalize, BlockFinder.hpp:91-97 */
-    void
-    finalize( std::optional<size_t> blockCount = {} )
-    {
-        stopThreads();
-        const std::lock_guard<std::mutex> hold( m_lock );
-        if ( blockCount ) {
-            if ( *blockCount > m_offsets.size() ) {
-                throw std::invalid_argument( "You may not finalize to a size larger than the current results buffer!" );
-            }
-            m_offsets.resize( *blockCount );
-        }
-        m_finalized = true;
-        m_wake.notify_all();
-    }
-
     [[nodiscard]] bool
-    finalized() const
+    complete() const
     {
-        return m_finalized;
+        const std::lock_guard<std::mutex> hold( m_lock );
+        return m_complete;
     }
 
-    /** BlockFinder::get, BlockFinder.hpp:112-131 + StreamedResults::get, StreamedResults.hpp:73-94 */
-    [[nodiscard]] std::pair<std::optional<size_t>, GetReturnCode>
-    get( size_t blockNumber, double timeoutInSeconds = std::numeric_limits<double>::infinity() )
+    /**
+     * Offset of block `number`.  Raises the scan's target to `number` + look-ahead, (re)starts the scan if the list is
+     * open, and waits up to `seconds` (DO_NOT_WAIT: look only; UNTIL_KNOWN: until the block is there or the list complete).
+     */
+    [[nodiscard]] Answer
+    at( size_t number, double seconds = UNTIL_KNOWN )
     {
-        if ( !m_finalized ) {
-            startThreads();
-        }
-        std::unique_lock<std::mutex> hold( m_lock );
-        m_highestRequested = std::max( m_highestRequested, blockNumber );
-        m_wake.notify_all();
-        if ( timeoutInSeconds > 0 ) {
-            const auto predicate = [&] () { return m_finalized.load() || ( blockNumber < m_offsets.size() ); };
-            if ( std::isfinite( timeoutInSeconds ) ) {
-                m_wake.wait_for( hold, std::chrono::nanoseconds( (int64_t)( timeoutInSeconds * 1e9 ) ), predicate );
-            } else {
-                m_wake.wait( hold, predicate );
+        std::vector<std::thread> finished;
+        Answer answer;
+        {
+            std::unique_lock<std::mutex> hold( m_lock );
+            if ( number > m_furthestAsked ) {
+                m_furthestAsked = number;
+                m_wake.notify_all();
             }
+            /* system_clock: waits on it are pthread_cond_timedwait, which ThreadSanitizer understands (waits on the steady
+             * clock go through pthread_cond_clockwait, which gcc 11's runtime does not intercept: false reports) */
+            const auto deadline = std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::nanoseconds>(
+                std::chrono::duration<double>( std::isinf( seconds ) ? 0. : std::max( 0., seconds ) ) );
+            const auto settled = [&] { return m_complete || ( number < m_offsets.size() ); };
+            for ( ;; ) {
+                if ( auto left = ensureScanning(); left.joinable() ) {
+                    finished.push_back( std::move( left ) );
+                }
+                /* a scan that was paused under a waiting reader is taken up again, hence `!m_scanning` */
+                const auto awake = [&] { return settled() || !m_scanning; };
+                if ( std::isinf( seconds ) ) {
+                    m_wake.wait( hold, awake );
+                } else if ( !settled() ) {
+                    if ( !( seconds > 0 ) || !m_wake.wait_until( hold, deadline, awake ) ) {
+                        break;
+                    }
+                }
+                if ( settled() ) {
+                    break;
+                }
+            }
+            if ( number < m_offsets.size() ) {
+                answer.bits = m_offsets[number];
+            }
+            answer.listComplete = m_complete;
         }
-        if ( blockNumber < m_offsets.size() ) {
-            return { m_offsets[blockNumber], GetReturnCode::SUCCESS };
+        for ( auto& thread : finished ) {
+            thread.join();
         }
-        return { std::nullopt, m_finalized ? GetReturnCode::FAILURE : GetReturnCode::TIMEOUT };
+        return answer;
     }
 
-    /** BlockFinder::find, BlockFinder.hpp:134-150 */
+    /** Number of the block that starts at `bits`; an offset that is not in the list is the caller's logic error. */
     [[nodiscard]] size_t
-    find( size_t encodedBlockOffsetInBits ) const
+    numberOf( size_t bits ) const
     {
         const std::lock_guard<std::mutex> hold( m_lock );
-        const auto match = std::lower_bound( m_offsets.begin(), m_offsets.end(), encodedBlockOffsetInBits );
-        if ( ( match == m_offsets.end() ) || ( *match != encodedBlockOffsetInBits ) ) {
-            throw std::out_of_range( "No block with the specified offset exists in the block finder map!" );
+        const auto [first, behind] = std::equal_range( m_offsets.begin(), m_offsets.end(), bits );
+        if ( first == behind ) {
+            throw std::out_of_range( "bit offset " + std::to_string( bits ) + " is not the start of a block in the finder's list of "
+                                     + std::to_string( m_offsets.size() ) + " blocks" );
         }
-        return (size_t)std::distance( m_offsets.begin(), match );
+        return (size_t)( first - m_offsets.begin() );
     }
 
-    /** BlockFinder::setBlockOffsets, BlockFinder.hpp:152-161 */
-    void
-    setBlockOffsets( std::deque<size_t> offsets )
+    /** The whole list at once; it is complete from here on.  False if a scanner came too late (see Authority). */
+    bool
+    adopt( std::vector<size_t> offsets, Authority who )
     {
-        stopThreads();
-        const std::lock_guard<std::mutex> hold( m_lock );
-        m_offsets = std::move( offsets );
-        m_finalized = true;
-        m_wake.notify_all();
+        std::thread scanner;
+        {
+            const std::lock_guard<std::mutex> hold( m_lock );
+            if ( m_complete && ( who == Authority::SCANNER ) ) {
+                return false;
+            }
+            m_offsets = std::move( offsets );
+            scanner = closeList();
+        }
+        if ( scanner.joinable() ) {
+            scanner.join();
+        }
+        return true;
+    }
+
+    /** The list ends after its first `count` blocks (what the scan saw behind them was no block), or where it is now. */
+    void
+    cut( std::optional<size_t> count = {} )
+    {
+        std::thread scanner;
+        {
+            const std::lock_guard<std::mutex> hold( m_lock );
+            if ( count ) {
+                if ( *count > m_offsets.size() ) {
+                    throw std::invalid_argument( "the finder's list has " + std::to_string( m_offsets.size() )
+                                                 + " blocks and cannot be cut to " + std::to_string( *count ) );
+                }
+                m_offsets.resize( *count );
+            }
+            scanner = closeList();
+        }
+        if ( scanner.joinable() ) {
+            scanner.join();
+        }
     }
 
 private:
-    /** BlockFinder::blockFinderMain, BlockFinder.hpp:164-197, scanning a chunk (not one match) per iteration. */
-    void
-    finderMain()
+    /** With m_lock held: nothing a running scan finds may be appended any more. */
+    [[nodiscard]] std::thread
+    closeList()
     {
-        constexpr uint64_t CHUNK = 8u << 20;
-        uint64_t position = 0;
-        {
-            const std::lock_guard<std::mutex> hold( m_lock );
-            position = m_scanPosition;
+        m_complete = true;
+        ++m_epoch;
+        m_wake.notify_all();
+        return std::move( m_thread );
+    }
+
+    /** With m_lock held.  Returns the handle of a thread that has left (paused earlier) for the caller to join. */
+    [[nodiscard]] std::thread
+    ensureScanning()
+    {
+        if ( m_complete || m_scanning ) {
+            return {};
         }
-        while ( true ) {
-            {
-                std::unique_lock<std::mutex> hold( m_lock );
-                m_wake.wait( hold, [this] {
-                    return m_cancel || ( m_offsets.size() <= m_highestRequested + m_prefetchCount );
-                } );
-                if ( m_cancel ) {
-                    m_scanPosition = position;
-                    return;
-                }
-            }
-            if ( position >= m_size ) {
+        std::thread finished = std::move( m_thread );
+        m_pause = false;
+        m_scanning = true;
+        m_thread = std::thread( [this, epoch = m_epoch] { scan( epoch ); } );
+        return finished;
+    }
+
+    /** The scan thread: a chunk of the file per round (split over m_scanThreads), as long as the list is `m_lookAhead`
+     * blocks or less ahead of the furthest block asked for. */
+    void
+    scan( const uint64_t epoch )
+    {
+        constexpr uint64_t CHUNK = 8U << 20U;
+        std::unique_lock<std::mutex> hold( m_lock );
+        const auto mine = [&] { return ( m_epoch == epoch ) && !m_pause; };
+        while ( mine() ) {
+            if ( m_scanPosition >= m_size ) {
+                m_complete = true;
                 break;
             }
-            const uint64_t end = std::min<uint64_t>( m_size, position + CHUNK * m_scanThreads );
+            if ( m_offsets.size() > m_furthestAsked + m_lookAhead ) {
+                m_wake.wait( hold );
+                continue;
+            }
+            const uint64_t begin = m_scanPosition;
+            const uint64_t end = std::min<uint64_t>( m_size, begin + CHUNK * m_scanThreads );
+            hold.unlock();
+
             std::vector<std::vector<uint64_t> > parts( m_scanThreads );
-            std::vector<std::thread> pool;
-            const uint64_t per = ( end - position + m_scanThreads - 1 ) / m_scanThreads;
+            std::vector<std::thread> helpers;
+            const uint64_t share = ( end - begin + m_scanThreads - 1 ) / m_scanThreads;
             for ( unsigned t = 0; t < m_scanThreads; ++t ) {
-                const uint64_t b = std::min( end, position + t * per );
-                const uint64_t e = std::min( end, b + per );
-                if ( t + 1 == m_scanThreads ) {
-                    scanMagicRange( m_bytes, m_size, m_magic, b, e, parts[t] );
+                const uint64_t from = std::min( end, begin + t * share );
+                const uint64_t to = std::min( end, from + share );
+                if ( t + 1 < m_scanThreads ) {
+                    helpers.emplace_back( [this, from, to, &parts, t] { scanMagicRange( m_bytes, m_size, m_magic, from, to, parts[t] ); } );
                 } else {
-                    pool.emplace_back( [this, b, e, &parts, t] () {
-                        scanMagicRange( m_bytes, m_size, m_magic, b, e, parts[t] );
-                    } );
+                    scanMagicRange( m_bytes, m_size, m_magic, from, to, parts[t] );
                 }
             }
-            for ( auto& th : pool ) {
-                th.join();
+            for ( auto& helper : helpers ) {
+                helper.join();
             }
-            position = end;
-            {
-                const std::lock_guard<std::mutex> hold( m_lock );
-                for ( const auto& part : parts ) {
-                    for ( const auto offset : part ) {
-                        m_offsets.push_back( offset );
-                    }
-                }
-                m_wake.notify_all();
+
+            hold.lock();
+            if ( m_epoch != epoch ) {
+                break;      /* the list was handed over or cut meanwhile: these matches belong to nobody */
             }
+            for ( const auto& part : parts ) {
+                m_offsets.insert( m_offsets.end(), part.begin(), part.end() );
+            }
+            m_scanPosition = end;
+            m_wake.notify_all();
         }
-        const std::lock_guard<std::mutex> hold( m_lock );
-        m_scanPosition = position;
-        m_finalized = true;
+        m_scanning = false;
         m_wake.notify_all();
     }
 
     const uint8_t* const m_bytes;
     const uint64_t m_size;
     const uint64_t m_magic;
-    const size_t m_prefetchCount;
+    const size_t m_lookAhead;
     const unsigned m_scanThreads;
 
     mutable std::mutex m_lock;
     std::condition_variable m_wake;
-    std::deque<size_t> m_offsets;
-    size_t m_highestRequested{ 0 };
-    uint64_t m_scanPosition{ 0 };
-    std::atomic<bool> m_finalized{ false };
-    bool m_cancel{ false };
-
-    std::mutex m_threadLock;
+    std::vector<size_t> m_offsets;      /* sorted: appended in file order or handed over whole */
+    size_t m_furthestAsked{ 0 };
+    uint64_t m_scanPosition{ 0 };       /* first byte the scan has not covered */
+    uint64_t m_epoch{ 0 };              /* advanced whenever the list changes hands */
+    bool m_complete{ false };
+    bool m_pause{ false };
+    bool m_scanning{ false };           /* a scan thread is inside scan() */
     std::thread m_thread;
 };
 }  // namespace mi355x

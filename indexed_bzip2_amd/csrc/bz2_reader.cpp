@@ -492,19 +492,18 @@ private:
             return m_stop;
         };
         while ( mi355x_bz2_input_resident( m_ctxs.front() ) == 0 ) {
-            if ( stopped() || m_finder->finalized() ) return;
+            if ( stopped() || m_finder->complete() ) return;
             std::this_thread::sleep_for( std::chrono::milliseconds( 2 ) );
         }
-        if ( stopped() || m_finder->finalized() ) return;
+        if ( stopped() || m_finder->complete() ) return;
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<uint64_t> offsets( (size_t)std::min<uint64_t>( m_source->size() / 6 + 16, 1u << 20 ) );
         uint64_t found = 0;
         if ( ( mi355x_bz2_find_magic_device( m_ctxs.front(), MI355X_BZ2_MAGIC_BLOCK, offsets.data(), offsets.size(),
                                              &found ) == MI355X_BZ2_OK ) && ( found <= offsets.size() ) ) {
             offsets.resize( found );
-            if ( !m_finder->finalized() ) {   /* an index given by the caller meanwhile stays */
-                m_finder->setBlockOffsets( std::deque<size_t>( offsets.begin(), offsets.end() ) );
-            }
+            /* an index given by the caller meanwhile, or a list cut behind trailing garbage, stays: decided inside the finder */
+            (void)m_finder->adopt( std::vector<size_t>( offsets.begin(), offsets.end() ), BlockFinder::Authority::SCANNER );
         }
         if ( m_trace ) {
             const auto now = std::chrono::steady_clock::now();
@@ -557,7 +556,7 @@ private:
         const auto wanted = m_pattern.ahead( m_window );
         if ( wanted.count == 0 ) return;
         size_t end = wanted.first + wanted.count;
-        if ( m_finder->finalized() ) end = std::min( end, m_finder->size() );
+        if ( m_finder->complete() ) end = std::min( end, m_finder->size() );
         /* the first block of the range that is neither finished nor in flight */
         size_t from = wanted.first;
         for ( ;; ) {
@@ -580,7 +579,7 @@ private:
         std::vector<uint64_t> offsets;
         for ( size_t b = from; b < from + room; ++b ) {
             if ( m_ready.covers( b ) || ( flightOf( b ) != m_flights.end() ) ) break;
-            const auto [offset, code] = m_finder->get( b, /* do not wait */ 0 );
+            const auto offset = m_finder->at( b, BlockFinder::DO_NOT_WAIT ).bits;
             if ( !offset ) break;
             offsets.push_back( *offset );
         }
@@ -592,7 +591,7 @@ private:
          * waits for, otherwise wait until a whole batch can go (the ramp's size while the reader starts up) -- unless nothing is
          * in flight at all or the file ends here. */
         const size_t worthIt = m_batch;
-        const bool reachesEnd = m_finder->finalized() && ( from + offsets.size() >= m_finder->size() );
+        const bool reachesEnd = m_finder->complete() && ( from + offsets.size() >= m_finder->size() );
         if ( somebodyWaits || ( offsets.size() >= std::min( worthIt, m_ramp ) ) || m_flights.empty() || reachesEnd ) {
             m_ramp = std::min( m_batch, 4 * m_ramp );
             m_stats.prefetches_submitted += offsets.size();
@@ -608,7 +607,7 @@ private:
     {
         std::vector<uint64_t> offsets;
         for ( size_t b = first; b < first + count; ++b ) {
-            const auto [offset, code] = m_finder->get( b );
+            const auto offset = m_finder->at( b ).bits;
             if ( !offset ) {
                 fail( MI355X_BZ2_ERR_LOGIC, "block " + std::to_string( b ) + " is not in the block finder's list" );
             }
@@ -871,7 +870,7 @@ public:
                 }
                 continue;
             }
-            const auto run = scheduler().demand( finder().find( span.bits ) );
+            const auto run = scheduler().demand( finder().numberOf( span.bits ) );
             const auto& record = recordIn( *run, span.bits );
             if ( record.status != MI355X_BZ2_OK ) {
                 fail( record.status, "block at bit offset " + std::to_string( span.bits ) );
@@ -964,7 +963,7 @@ public:
     {
         if ( !m_index.sealed() ) {
             read( Sink() );
-            if ( !m_index.sealed() || !finder().finalized() ) {
+            if ( !m_index.sealed() || !finder().complete() ) {
                 fail( MI355X_BZ2_ERR_LOGIC, "the whole file was read but its block index is not complete" );
             }
         }
@@ -1035,7 +1034,7 @@ private:
     indexNextBlock()
     {
         const size_t number = m_index.dataBlocks();
-        const auto bits = finder().get( number ).first;
+        const auto bits = finder().at( number ).bits;
         if ( !bits ) {
             m_index.seal();
             return false;
@@ -1069,7 +1068,7 @@ private:
         if ( ( behind < m_source->sizeInBits() )
              && ( mi355x_bz2_read_stream_header( m_source->bytes(), m_source->size(), behind ) == 0 ) ) {
             std::cerr << "[Warning] Trailing garbage after EOF ignored!\n";
-            m_finder->finalize( m_index.dataBlocks() );   /* whatever the finder saw in the garbage is not a block */
+            m_finder->cut( m_index.dataBlocks() );   /* whatever the finder saw in the garbage is not a block */
         }
         return true;
     }
@@ -1097,7 +1096,7 @@ private:
         if ( !m_scheduler ) {
             (void)finder();
             m_scheduler = std::make_unique<BatchScheduler>( m_source, m_finder, m_batch, m_device );
-            if ( !m_finder->finalized() ) {
+            if ( !m_finder->complete() ) {
                 m_finder->startThreads();
             }
         }
@@ -1110,13 +1109,13 @@ private:
         if ( offsets.empty() ) {
             fail( MI355X_BZ2_ERR_INVALID_ARGUMENT, "a list of block offsets is required" );
         }
-        std::deque<size_t> dataBlocks;
+        std::vector<size_t> dataBlocks;
         for ( auto entry = offsets.begin(), behind = std::next( entry ); behind != offsets.end(); ++entry, ++behind ) {
             if ( entry->second != behind->second ) {
                 dataBlocks.push_back( entry->first );
             }
         }
-        finder().setBlockOffsets( std::move( dataBlocks ) );
+        (void)finder().adopt( std::move( dataBlocks ), BlockFinder::Authority::CALLER );
     }
 
 private:

@@ -65,18 +65,35 @@ int main() {
     {
         BlockFinder finder(buf.data(), buf.size(), MI355X_BZ2_MAGIC_BLOCK, 8, 2);
         finder.startThreads();
-        for (size_t i = 0; i < want.size(); ++i) { const auto [o, code] = finder.get(i); assert(o && *o == want[i]); }
-        const auto [none, code] = finder.get(want.size());
-        assert(!none && code == BlockFinder::GetReturnCode::FAILURE);
-        assert(finder.find(want[3]) == 3);
+        for (size_t i = 0; i < want.size(); ++i) { const auto a = finder.at(i); assert(a.bits && *a.bits == want[i]); }
+        const auto none = finder.at(want.size());
+        assert(!none.bits && none.listComplete);
+        assert(finder.numberOf(want[3]) == 3);
+        bool threw = false;
+        try { (void)finder.numberOf(want[3] + 1); } catch (const std::out_of_range&) { threw = true; }
+        assert(threw);
     }
     {
         BlockFinder finder(buf.data(), buf.size(), MI355X_BZ2_MAGIC_BLOCK, 2, 1);
-        (void)finder.get(1);
-        finder.finalize(2);
-        assert(finder.size() == 2 && finder.finalized());
-        finder.setBlockOffsets({1, 2, 3});
-        assert(finder.size() == 3);
+        (void)finder.at(1);
+        const auto early = finder.at(1000, BlockFinder::DO_NOT_WAIT);
+        assert(!early.bits);
+        finder.cut(2);
+        assert(finder.size() == 2 && finder.complete());
+        assert(!finder.adopt({7, 8, 9, 10}, BlockFinder::Authority::SCANNER));      // too late: the cut list stays
+        assert(finder.size() == 2);
+        assert(finder.adopt({1, 2, 3}, BlockFinder::Authority::CALLER));
+        assert(finder.size() == 3 && finder.numberOf(3) == 2);
+        bool threw = false;
+        try { finder.cut(4); } catch (const std::invalid_argument&) { threw = true; }
+        assert(threw);
+    }
+    {   // paused and resumed
+        BlockFinder finder(buf.data(), buf.size(), MI355X_BZ2_MAGIC_BLOCK, 1, 1);
+        (void)finder.at(0);
+        finder.stopThreads();
+        const auto a = finder.at(want.size() - 1);
+        assert(a.bits && *a.bits == want.back());
     }
     std::printf("host ok\n");
     return 0;

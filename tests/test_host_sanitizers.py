@@ -20,6 +20,10 @@ CASES = [
     ("host_sanitize.cpp", "thread", [], "host ok"),                      # the finder thread against its consumers
     ("finder_sanitize.cpp", "thread", [], "matches"),
     ("host_known_answers.cpp", "address,undefined", [VECTORS], "known answers ok"),
+    # asking threads against a hand-over / an import / a cut of the list at a random moment (the round-2 finder restarted its
+    # scan behind a complete list: this harness shows that within ten rounds on that code)
+    ("finder_race.cpp", "thread", ["60"], "finder race ok"),
+    ("finder_race.cpp", "address,undefined", ["120"], "finder race ok"),
 ]
 
 
