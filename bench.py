@@ -40,9 +40,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(total_bytes, base_bytes, cache_dir, rank, world, barrier):
-    """Rank 0 builds (or finds cached) the .bz2 file; everyone loads it."""
-    key = f"silesia_like-{base_bytes}-x{total_bytes}-l9-v3"
+def build_workload(total_bytes, base_bytes, cache_dir, rank, world, barrier, kind="silesia"):
+    """Rank 0 builds (or finds cached) the .bz2 file; everyone loads it.  kind "urandom" = config 3 of BASELINE.json
+    (seeded random bytes: incompressible), for tools/bench_configs.py."""
+    key = f"silesia_like-{base_bytes}-x{total_bytes}-l9-v3" if kind == "silesia" else f"urandom-{base_bytes}-x{total_bytes}-l9-v3"
     path = os.path.join(cache_dir, key + ".bz2")
     meta_path = path + ".json"
     if rank == 0 and not (os.path.exists(path) and os.path.exists(meta_path)):
@@ -51,7 +52,11 @@ def build_workload(total_bytes, base_bytes, cache_dir, rank, world, barrier):
         import indexed_bzip2_amd as m
         os.makedirs(cache_dir, exist_ok=True)
         t0 = time.time()
-        base = silesia_like.generate(base_bytes, threads=min(16, os.cpu_count() or 8))
+        if kind == "silesia":
+            base = silesia_like.generate(base_bytes, threads=min(16, os.cpu_count() or 8))
+        else:
+            import numpy
+            base = numpy.random.Generator(numpy.random.PCG64(0xBADC0DE)).integers(0, 256, base_bytes, dtype=numpy.uint8)
         repeat = max(1, total_bytes // base_bytes)
         t1 = time.time()
         streams = bz2build.compress_pieces(base, piece_size=9_000_000, level=9, threads=min(32, os.cpu_count() or 8))
@@ -130,6 +135,10 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("BZ2_BENCH_CACHE", "/tmp/indexed_bzip2_amd_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-host-output", action="store_true", help="skip the decoded-bytes-in-host-memory figure")
+    ap.add_argument("--workload", default="silesia", choices=["silesia", "urandom"],
+                    help="silesia = the headline workload (config 4 of BASELINE.json); urandom = config 3 (2 GiB of seeded "
+                         "random bytes at bzip2 -9: incompressible), used by tools/bench_configs.py")
     ap.add_argument("--weak", action="store_true",
                     help="round-1 mode: every rank decodes its own whole copy of the file (per-GPU work fixed)")
     ap.add_argument("--resident", action="store_true",
@@ -182,7 +191,7 @@ def main():
     from indexed_bzip2_amd.distributed import (shard_blocks, shard_byte_range, gather_extents, crc_chain,
                                                combine_crc_chains)
 
-    path, enc, meta = build_workload(args.total_bytes, args.base_bytes, args.cache_dir, rank, world, barrier)
+    path, enc, meta = build_workload(args.total_bytes, args.base_bytes, args.cache_dir, rank, world, barrier, args.workload)
     offsets = meta["offsets"]
     n_file_blocks = len(offsets)
     file_decoded = meta["decoded_bytes"]
@@ -216,12 +225,14 @@ def main():
     chain = crc_chain(r["computed_crc"] for r in results)
     if world > 1:
         parts = [None] * world
-        dist.all_gather_object(parts, (chain, n_blocks, my_decoded))
+        # (the block sizes and checksums of every rank: rank 0 checks the bytes that ARRIVE in its gather buffer against them)
+        dist.all_gather_object(parts, (chain, n_blocks, my_decoded,
+                                       [(r["decoded_size"], r["computed_crc"]) for r in results] if strong else None))
     else:
-        parts = [(chain, n_blocks, my_decoded)]
+        parts = [(chain, n_blocks, my_decoded, None)]
     extent_sizes = [p[2] for p in parts]
     if strong:
-        stream_crc = combine_crc_chains((c, n) for c, n, _ in parts)
+        stream_crc = combine_crc_chains((p[0], p[1]) for p in parts)
         assert sum(p[2] for p in parts) == file_decoded, (parts, file_decoded)
     else:
         stream_crc = chain
@@ -261,23 +272,58 @@ def main():
             gather_done[id(decoder)] = done
             decoder.hold_output_until(done.cuda_event, keepalive=done)
 
+    # ---- content check of the gather, once, outside the timed region: every block of every peer, as it lies in rank 0's
+    # gather buffer, has the checksum its sender computed (= the one stored in the file: status OK above) ----
+    gathered_blocks_checked = 0
+    if world > 1 and strong and not args.no_gather:
+        gather(my_decoded, dec)
+        pending = gather_done.pop(id(dec), None)
+        if pending is not None:
+            pending.synchronize()
+        if rank == 0:
+            received = gather_buf if gather_buf.is_cuda else gather_buf.cuda()
+            torch.cuda.synchronize()
+            at = 0
+            for r in range(1, world):
+                blocks = parts[r][3]
+                assert sum(size for size, _ in blocks) == extent_sizes[r]
+                # the extent of rank r starts at `at`; k_crc wants a 16-byte aligned base: checksum from an aligned copy if not
+                extent = received[at:at + extent_sizes[r]]
+                if extent.data_ptr() % 16:
+                    extent = extent.clone()
+                got = dec.crc32_device(extent.data_ptr(), [size for size, _ in blocks])
+                want = [crc for _, crc in blocks]
+                assert got == want, f"gathered extent of rank {r}: {sum(a != b for a, b in zip(got, want))} blocks differ"
+                gathered_blocks_checked += len(blocks)
+                at += extent_sizes[r]
+            log(f"[bench] gather verified: {gathered_blocks_checked} blocks of {world - 1} peers have their senders' checksums")
+        barrier()
+
     offs_c, _ = dec.make_arrays(my_offsets)
     res_cs = [d.make_arrays(my_offsets)[1] for d in decs]
     status_views = [np.frombuffer(r, dtype=np.int32).reshape(max(n_blocks, 1), -1)[:, -1] for r in res_cs]   # BlockResult.status
     resident_in = None
 
-    def finish(k):
-        """Second half of step k on its context: output offsets, expansion, CRC; every block's status checked; decoded
-        extents gathered for N > 1."""
+    host_out = []          # page-locked host buffers, one per context, for the "decoded bytes in host memory" figure
+
+    def finish(k, to_host=False):
+        """Second half of step k on its context: every block's status checked; decoded extents gathered for N > 1, or
+        (to_host) copied to page-locked host memory in the background, beside the context's next step."""
         d = decs[k % len(decs)]
         pending = gather_done.pop(id(d), None)
         if pending is not None:
             pending.synchronize()   # long finished in practice: a whole step has passed
+        if to_host:
+            d.copy_output_end()     # the copy of this context's previous step: its host buffer is written again below
         total = d.end_batch(res_cs[k % len(decs)])
         assert total == my_decoded and not status_views[k % len(decs)].any(), "a block failed"
-        gather(total, d)
+        if to_host:
+            buf = host_out[k % len(decs)]
+            d.copy_output_begin_to(0, total, buf.data_ptr(), keepalive=buf)
+        else:
+            gather(total, d)
 
-    def run_steps(count, resident=False):
+    def run_steps(count, resident=False, to_host=False):
         """`count` passes of the hot path, each through the C ABI with preallocated arrays (no per-block Python
         objects).  A pass = the H2D copy of the compressed bytes, then the batch.  With several contexts step k+1 is
         queued before step k is finished, and the copy for a context's next step is queued as soon as its current step
@@ -289,7 +335,7 @@ def main():
         stagger = float(os.environ.get("BENCH_STAGGER_MS", "0")) / 1e3   # development: pause between the first launches
         for k in range(count + depth):
             if k >= depth:                       # step k - depth holds the context that step k needs
-                finish(k - depth)
+                finish(k - depth, to_host)
                 gpu_ms += decs[(k - depth) % depth].pipeline_ms()
             if k < count:
                 d = decs[k % depth]
@@ -301,6 +347,9 @@ def main():
                 if not resident and prefetch and k + depth < count:
                     # the bytes of this context's NEXT step (step k + depth): their copy runs beside the kernels of this one
                     d.set_input_host_async(host_ptr, my_bytes, keepalive=host_in)
+        if to_host:
+            for d in decs:
+                d.copy_output_end()
         return gpu_ms
 
     run_steps(max(len(decs), args.warmup - 1))   # warm-up; also sizes the scratch of every context
@@ -308,11 +357,11 @@ def main():
     alg_bytes = sum(r["encoded_size_bits"] / 8 + 10 * r["bwt_length"] + r["decoded_size"] for r in results)
     io_floor = sum(r["encoded_size_bits"] / 8 + r["decoded_size"] for r in results)
 
-    def timed(count, resident=False):
+    def timed(count, resident=False, to_host=False):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        gpu_ms = run_steps(count, resident)
+        gpu_ms = run_steps(count, resident, to_host)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
@@ -336,6 +385,33 @@ def main():
         resident_steps = max(2, min(10, args.steps))      # enough steps for the contexts' pipeline to fill
         resident_dt, _ = timed(resident_steps, resident=True)
 
+    # second figure of SURVEY 8(d): "decoded bytes in host memory" -- every step's output copied to page-locked host memory
+    # (mi355x_bz2_copy_output_begin / _end: on a copy stream, beside the context's next step); single GPU only
+    host_dt = host_steps = None
+    if world == 1 and not args.resident and not args.no_host_output:
+        host_out.extend(torch.empty(my_decoded, dtype=torch.uint8).pin_memory() for _ in decs)
+        run_steps(len(decs), to_host=True)
+        host_steps = max(2, min(10, args.steps))
+        host_dt, _ = timed(host_steps, to_host=True)
+        # the bytes that arrived: head and tail of the last step's buffer against the device's
+        last = host_out[(host_steps - 1) % len(decs)]
+        assert bytes(last[:4096].numpy()) == decs[(host_steps - 1) % len(decs)].copy_output(0, 4096)
+        assert bytes(last[my_decoded - 4096:].numpy()) == decs[(host_steps - 1) % len(decs)].copy_output(my_decoded - 4096, 4096)
+        host_out.clear()
+    # every kernel launched ONCE over the whole batch, nothing beside it (no block groups, one context, input resident):
+    # the per-kernel durations that mean something on their own
+    alone = None
+    if world == 1:
+        os.environ["MI355X_BZ2_NO_SPLIT"] = "1"
+        try:
+            d0 = decs[0]
+            for _ in range(2):
+                d0.begin_batch(offs_c, n_blocks)
+                d0.end_batch(res_cs[0])
+            alone = d0.timings()
+        finally:
+            del os.environ["MI355X_BZ2_NO_SPLIT"]
+
     if rank == 0:
         steps = args.steps
         job_decoded = file_decoded if strong else file_decoded * world
@@ -352,14 +428,16 @@ def main():
         # PMC traffic of one step of this workload (tools/profile_round.sh traffic: separate FETCH_SIZE / WRITE_SIZE passes,
         # corrected as calibrated by tools/fetch_calib.sh), measured for the single-GPU case
         tpath = os.path.join(ROOT, "profiles", "r02_traffic_bench.json")
-        if os.path.exists(tpath) and world == 1 and n_blocks == 2560:
+        if os.path.exists(tpath) and world == 1 and n_blocks == 2560 and args.workload == "silesia":
             traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         out = {
-            "metric": "decompressed MB/s (whole node), 2 GiB Silesia bz2-9",
+            "metric": "decompressed MB/s (whole node), 2 GiB Silesia bz2-9" if args.workload == "silesia"
+                      else "decompressed MB/s, 2 GiB urandom bz2-9 (config 3)",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"silesia-style corpus ({args.base_bytes / 1e6:.0f} MB, seed 0x51E51A) repeated to "
+            "config": {"workload": (f"silesia-style corpus ({args.base_bytes / 1e6:.0f} MB, seed 0x51E51A)" if args.workload == "silesia"
+                                    else f"PCG64(0xBADC0DE) random bytes ({args.base_bytes / 1e6:.0f} MB)") + " repeated to "
                                    f"{file_decoded / 2**30:.2f} GiB, ONE single-stream bzip2 -9 file, {n_file_blocks} blocks, "
                                    f"{len(enc) / 1e6:.0f} MB compressed" + ("" if strong else ", one whole copy per GPU"),
                        "blocks_rank0": n_blocks, "compressed_bytes_rank0": my_bytes, "decoded_bytes_rank0": my_decoded,
@@ -368,6 +446,7 @@ def main():
                                        f"compressed size" if strong else f"every one of {world} GPU(s) decodes a whole copy")
                                       + ("" if world == 1 or args.no_gather else ", RCCL gather of decoded extents to rank 0"),
                        "decoder_contexts": len(decs),
+                       "gathered_blocks_verified_on_rank0": gathered_blocks_checked if world > 1 else None,
                        "input_resident_in_hbm": bool(args.resident), "output_left_in_hbm": True,
                        "step": ("compressed bytes resident in HBM -> decoded bytes in HBM" if args.resident else
                                 "compressed bytes in page-locked host memory -> H2D (on the context's input stream, beside the "
@@ -381,13 +460,25 @@ def main():
                                        "region / steps), the region being device-synchronized on both sides.  "
                                        "pipeline_ms_per_step = HIP events on the launch streams from before the first to "
                                        "after the last kernel of a step; with two contexts consecutive steps overlap, so "
-                                       "these add up to more than the region.  kernels_ms = per-kernel event durations of "
-                                       "the last step SUMMED over its block groups, which run on separate streams "
-                                       "concurrently: a sum can exceed ms_per_step (e.g. four overlapping k_hscan launches)",
+                                       "these add up to more than the region.  kernels_ms = HIP-event duration of every "
+                                       "kernel launched ONCE over the whole batch with nothing beside it (no block groups, "
+                                       "one context, input resident; measured after the timed region); "
+                                       "kernels_ms_in_the_crowd = durations of the last timed step summed over its block "
+                                       "groups, which run concurrently on separate streams beside three other steps (a sum "
+                                       "can exceed ms_per_step)",
                          "pipeline_ms_per_step": round(pipeline_ms, 3),
                          "kernel_ms_sum_per_step": round(kernel_ms, 3), "dominant_kernel": dom,
-                         "kernels_ms": {k: round(v, 3) for k, v in ksum.items()}},
+                         "kernels_ms": {k: round(v, 3) for k, v in (alone["kernels"] if alone else ksum).items() if v > 0},
+                         "kernels_ms_in_the_crowd": {k: round(v, 3) for k, v in ksum.items() if v > 0}},
         }
+        if alone:
+            out["roofline"]["kernel_ms_sum_alone"] = round(alone["ms_kernel_sum"], 3)
+            out["roofline"]["dominant_kernel"] = max(alone["kernels"], key=alone["kernels"].get)
+        if host_dt is not None:
+            out["config"]["host_output_MBps"] = round(job_decoded * host_steps / host_dt / 1e6, 1)
+            out["config"]["host_output_ms_per_step"] = round(host_dt / host_steps * 1e3, 3)
+            out["config"]["host_output"] = ("same steps, each step's decoded bytes copied to page-locked host memory on a copy "
+                                            "stream beside the context's next step (mi355x_bz2_copy_output_begin/_end)")
         if resident_dt is not None:
             out["config"]["resident_input_MBps"] = round(job_decoded * resident_steps / resident_dt / 1e6, 1)
             out["config"]["resident_input_ms_per_step"] = round(resident_dt / resident_steps * 1e3, 3)

@@ -14,11 +14,11 @@
  *        replaces  BitStringFinder<48>::find             src/core/BitStringFinder.hpp:158-285
  *                  ParallelBitStringFinder<48>::find     src/core/ParallelBitStringFinder.hpp:159-265
  *   3. Reader (scheduler + block map + user API):        mi355x_bz2_reader_*
- *   4. Chunk decoding for rapidgzip:                     mi355x_bz2_decode_chunk
- *        replaces  Bzip2Chunk::decodeChunk               src/rapidgzip/chunkdecoding/Bzip2Chunk.hpp:34-268
  *        replaces  indexed_bzip2::ParallelBZ2Reader      src/indexed_bzip2/ParallelBZ2Reader.hpp:39-498
  *                  (BZ2ReaderInterface                   src/indexed_bzip2/BZ2ReaderInterface.hpp:15-103)
  *        as bound by the Cython module                   python/indexed_bzip2/indexed_bzip2.pyx:26-67
+ *   4. Chunk decoding for rapidgzip:                     mi355x_bz2_decode_chunk
+ *        replaces  Bzip2Chunk::decodeChunk               src/rapidgzip/chunkdecoding/Bzip2Chunk.hpp:34-268
  *
  * No exceptions cross this ABI: every reference throw site on the path has a status code below; the host-side
  * scheduler turns a non-OK status back into the reference's behaviour (prefetch failures are silent, on-demand
@@ -165,12 +165,21 @@ int mi355x_bz2_share_input( mi355x_bz2_ctx* ctx, mi355x_bz2_ctx* from );
 int mi355x_bz2_decode_batch( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offsets, uint32_t n_blocks,
                              mi355x_bz2_block_result* results, uint64_t* total_decoded );
 
-/* The same in two halves, for callers that keep the GPU busy across batches: _begin plans the batch and queues
- * everything up to the decoded sizes (k_huff .. k_rle<false>) without waiting, _end waits for those, assigns the output
- * offsets, runs the expansion and the CRC and fills `results` (n entries as given to _begin).  One batch per context
- * can be in flight; two contexts used alternately (begin(A), begin(B), end(A), begin(A'), end(B), ...) overlap the
- * Huffman stage of one batch with the throughput kernels of the other.  Each context drives 4 HIP streams: with two
- * of them set GPU_MAX_HW_QUEUES=16 before the HIP runtime starts, or streams share hardware queues and serialize. */
+/* The same in two halves, for callers that keep the GPU busy across batches.
+ *   _begin plans the batch and queues ALL of it without waiting: the group-start scan, symbols, MTF, table build, walk,
+ *          the output offsets (computed on the device, k_offsets), the run-length expansion into the output buffer, the
+ *          CRC, and the copy of the block records to the host.  The output buffer is chosen here for 900 000 bytes per
+ *          block; a mi355x_bz2_hold_output_until event given before _begin is waited for by the output kernels only.
+ *   _end   waits for the batch and fills `results` (n entries, in the order given to _begin).  Only when the batch
+ *          decoded to more than the buffer chosen in _begin (blocks beyond the usual 900 000 bytes) does it repeat the
+ *          expansion and the CRC with a buffer of the right size.
+ * One batch per context can be in flight; contexts used in turn (begin(A), begin(B), end(A), begin(A'), end(B), ...)
+ * overlap the latency-bound first kernels of one batch with the throughput kernels of the others.  The input of the NEXT
+ * batch may be queued while one is in flight (mi355x_bz2_set_input_host_async: second input buffer, stream of its own).
+ * A context drives up to nine HIP streams (up to four block groups and, for small batches, a side stream each for the
+ * second k_mtf instance; one stream each for input copies, output copies and the device magic scan): set
+ * GPU_MAX_HW_QUEUES (16 measured best for four contexts) before the HIP runtime starts, or streams share hardware queues
+ * and serialize. */
 int mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* ctx, const uint64_t* block_bit_offsets, uint32_t n_blocks );
 int mi355x_bz2_decode_batch_end( mi355x_bz2_ctx* ctx, mi355x_bz2_block_result* results, uint64_t* total_decoded );
 
@@ -202,6 +211,15 @@ void* mi355x_bz2_stream( const mi355x_bz2_ctx* ctx );
  * batch to host. stage 0 = L column (N bytes, bzip2.hpp:789 dbuf low bytes), 1 = packed LF table (4N bytes),
  * 2 = inverse-BWT output before RLE1 (N bytes). */
 int mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* ctx, uint32_t index, int stage, void* host_dst, uint64_t capacity );
+
+/* bzip2's CRC-32 (MSB-first, polynomial 0x04C11DB7, createCRC32LookupTable / updateCRC32, bzip2.hpp:59-91, with the
+ * initial value and final inversion of bzip2.hpp:833, 901) of `n_pieces` consecutive pieces of a DEVICE buffer: piece i
+ * is the `sizes[i]` bytes behind the pieces in front of it.  For consumers of decoded extents that sit on another GPU
+ * (the gather of bench.py): the receiver recomputes every block's checksum over the bytes that ARRIVED and compares it
+ * with the checksum the sender's block record carries.  `device_bytes` must be 16-byte aligned; runs on the context's
+ * stream and waits for the result; no batch may be in flight on the context. */
+int mi355x_bz2_crc32_device( mi355x_bz2_ctx* ctx, const void* device_bytes, const uint64_t* sizes, uint32_t n_pieces,
+                             uint32_t* crcs );
 
 /* ------------------------------------------------------------------------------------------------ 2. magic scan */
 

@@ -114,6 +114,7 @@ SYMBOLS = [
                                                  ctypes.c_uint64, ctypes.c_uint32]),
     ("mi355x_bz2_share_input", ctypes.c_int, [_vp, _vp]),
     ("mi355x_bz2_find_magic_device", ctypes.c_int, [_vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, _u64p]),
+    ("mi355x_bz2_crc32_device", ctypes.c_int, [_vp, _vp, _u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]),
     ("mi355x_bz2_read_stream_header", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
     ("mi355x_bz2_reader_open_path", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
     ("mi355x_bz2_reader_open_fd", ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(_vp)]),
@@ -310,6 +311,14 @@ class Decoder:
         self._check(lib().mi355x_bz2_find_magic_device(self._h, magic, arr, n.value, ctypes.byref(n)))
         return list(arr[:n.value])
 
+    def crc32_device(self, device_ptr: int, sizes):
+        """bzip2 CRC-32 of consecutive pieces (`sizes` bytes each) of a 16-byte aligned device buffer."""
+        n = len(sizes)
+        arr = (ctypes.c_uint64 * max(1, n))(*sizes)
+        out = (ctypes.c_uint32 * max(1, n))()
+        self._check(lib().mi355x_bz2_crc32_device(self._h, ctypes.c_void_p(device_ptr), arr, n, out))
+        return list(out[:n])
+
     def output_device_ptr(self) -> int:
         return lib().mi355x_bz2_output_device(self._h) or 0
 
@@ -327,6 +336,11 @@ class Decoder:
         buf = (ctypes.c_ubyte * max(1, size))()
         self._check(lib().mi355x_bz2_copy_output_begin(self._h, offset, size, buf))
         return buf
+
+    def copy_output_begin_to(self, offset: int, size: int, host_ptr: int, keepalive=None):
+        """The same into caller-owned (page-locked) host memory at address `host_ptr`; valid after copy_output_end()."""
+        self._copy_ref = keepalive
+        self._check(lib().mi355x_bz2_copy_output_begin(self._h, offset, size, ctypes.c_void_p(host_ptr)))
 
     def copy_output_end(self):
         self._check(lib().mi355x_bz2_copy_output_end(self._h))

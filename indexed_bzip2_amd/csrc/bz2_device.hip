@@ -1069,6 +1069,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
     const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
     const uint32_t scanGrid = sg != nullptr ? (uint32_t)std::atoi( sg ) : 0u;
+    const char* smx = std::getenv( "MI355X_BZ2_SCAN_MIXED" );   /* 0: off; 4 / 8: that many waves per expensive block; default: by count */
+    const uint32_t scanMixed = smx != nullptr ? (uint32_t)std::atoi( smx ) : 1u;
     const char* wsr = std::getenv( "MI355X_BZ2_WALK_SERIAL" );
     const bool walkSerial = !( wsr != nullptr && wsr[0] == '0' );
     const char* mn = std::getenv( "MI355X_BZ2_MTF_NARROW" );   /* 1: 256 lanes per block in k_mtf whatever the batch size */
@@ -1112,8 +1114,14 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
              * group and the barriers grow with the waves); eight are faster than four for ONE batch of 320 blocks (15 vs
              * 18 ms) but slower when four such batches run side by side (14.5 vs 13.4 ms per batch): eight up to 384
              * blocks for a caller with one or two contexts, up to 128 in a crowd */
-            const uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves
-                                                            : ( n <= ( crowd ? 128u : 384u ) ? 8u : ( n <= 1280 ? 4u : 1u ) );
+            /* In a big batch the launch of one wave per block lasts as long as its largest block's chain (34 ms for an
+             * incompressible block, against 14.6 ms of average wave life): the expensive minority gets its own waves per
+             * group (MI355X_BZ2_SCAN_MIXED=0: one wave per block for them too) */
+            uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves
+                                                      : ( n <= ( crowd ? 128u : 384u ) ? 8u : ( n <= 1280 ? 4u : 1u ) );
+            if ( forcedScanWaves == 0 && scanWaves == 1 && g == expensiveGroup && scanMixed != 0 ) {
+                scanWaves = scanMixed >= 4 ? scanMixed : ( m <= 128 ? 8u : 4u );
+            }
             const auto* const inWords = reinterpret_cast<const uint32_t*>( inBase );
             if ( scanWaves >= 8 && scanSpec ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
@@ -1507,6 +1515,53 @@ mi355x_bz2_find_magic_device( mi355x_bz2_ctx* c, uint64_t magic48, uint64_t* bit
     std::sort( host.begin(), host.end() );
     *nFound = host.size();
     for ( uint64_t i = 0; i < host.size() && i < capacity; ++i ) bitOffsets[i] = host[i];
+    return MI355X_BZ2_OK;
+}
+
+int
+mi355x_bz2_crc32_device( mi355x_bz2_ctx* c, const void* deviceBytes, const uint64_t* sizes, uint32_t nPieces, uint32_t* crcs )
+{
+    if ( c == nullptr || ( nPieces > 0 && ( deviceBytes == nullptr || sizes == nullptr || crcs == nullptr ) ) ) {
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    if ( nPieces == 0 ) return MI355X_BZ2_OK;
+    const std::scoped_lock lock( c->mutex );
+    if ( c->pendingBlocks != 0 || ( reinterpret_cast<uintptr_t>( deviceBytes ) & 15u ) != 0 ) {
+        c->lastError = "crc32_device: a batch is in flight, or the buffer is not 16-byte aligned";
+        return MI355X_BZ2_ERR_INVALID_ARGUMENT;
+    }
+    HIP_TRY( c, hipSetDevice( c->device ) );
+    /* k_crc as it runs behind a batch, over records that describe the pieces */
+    std::vector<BlockMeta> records( nPieces );
+    uint64_t at = 0;
+    for ( uint32_t i = 0; i < nPieces; ++i ) {
+        BlockMeta m{};
+        m.decoded_size = sizes[i];
+        m.out_off = at;
+        m.walk_ok = 1;
+        records[i] = m;
+        at += sizes[i];
+    }
+    BlockMeta* dRecords = nullptr;
+    HIP_TRY( c, hipMalloc( &dRecords, (size_t)nPieces * sizeof( BlockMeta ) ) );
+    int rc = MI355X_BZ2_OK;
+    if ( hipMemcpyAsync( dRecords, records.data(), (size_t)nPieces * sizeof( BlockMeta ), hipMemcpyHostToDevice, c->stream ) != hipSuccess ) {
+        rc = MI355X_BZ2_ERR_DEVICE;
+    } else {
+        hipLaunchKernelGGL( k_crc, dim3( nPieces ), dim3( CRC_THREADS ), 0, c->stream, dRecords,
+                            static_cast<const uint8_t*>( deviceBytes ), c->crc, static_cast<const uint64_t*>( nullptr ) );
+        if ( hipGetLastError() != hipSuccess
+             || hipMemcpyAsync( records.data(), dRecords, (size_t)nPieces * sizeof( BlockMeta ), hipMemcpyDeviceToHost, c->stream ) != hipSuccess
+             || hipStreamSynchronize( c->stream ) != hipSuccess ) {
+            rc = MI355X_BZ2_ERR_DEVICE;
+        }
+    }
+    (void)hipFree( dRecords );
+    if ( rc != MI355X_BZ2_OK ) {
+        c->lastError = "crc32_device: the checksum kernel failed";
+        return rc;
+    }
+    for ( uint32_t i = 0; i < nPieces; ++i ) crcs[i] = records[i].computed_crc;
     return MI355X_BZ2_OK;
 }
 

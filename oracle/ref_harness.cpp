@@ -18,11 +18,18 @@
  *   probe  <file> <bitOffset>   decode one block at an arbitrary bit offset; prints OK ... or EXC <type> <what>
  *   decode <file> <P> <out>     full decode to <out> ("-" = discard)
  *   bench  <file> <P> <reps> [maxBytes]   decode-only timing; prints JSON
+ *   pread  <file> <index> <positions> <P> <bytes>   config 5 of BASELINE.json on the reference: ParallelBZ2Reader with the
+ *                               block map of <index> ("<bits> <bytes>" lines, as `map` prints) imported through
+ *                               setBlockOffsets (ParallelBZ2Reader.hpp:365-378), then seek + read(<bytes>) at every
+ *                               decoded offset listed in <positions> (ParallelBZ2Reader.hpp:271-325, 167-265); prints
+ *                               JSON with the latency percentiles and FNV-64 / zlib CRC-32 over all bytes read
  */
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -194,6 +201,69 @@ main( int argc, char** argv )
             }
             std::printf( "{\"decoded_bytes\": %zu, \"seconds\": %.6f, \"MBps\": %.3f, \"P\": %zu, \"reps\": %d}\n",
                          total, best, total / best / 1e6, P, reps );
+            return 0;
+        }
+        if ( cmd == "pread" ) {
+            if ( argc < 7 ) {
+                std::fprintf( stderr, "usage: pread <file> <index> <positions> <P> <bytes>\n" );
+                return 2;
+            }
+            std::map<size_t, size_t> offsets;
+            {
+                std::ifstream in( argv[3] );
+                size_t bits = 0, bytes = 0;
+                while ( in >> bits >> bytes ) offsets.emplace( bits, bytes );
+            }
+            std::vector<size_t> positions;
+            {
+                std::ifstream in( argv[4] );
+                size_t at = 0;
+                while ( in >> at ) positions.push_back( at );
+            }
+            const size_t P = std::stoul( argv[5] );
+            const size_t nBytes = std::stoull( argv[6] );
+            const auto tOpen = std::chrono::steady_clock::now();
+            ParallelBZ2Reader reader( openFile( path ), P );
+            reader.setBlockOffsets( offsets );
+            std::vector<char> buffer( nBytes );
+            std::vector<double> latencies;
+            latencies.reserve( positions.size() );
+            uint64_t hash = 0xcbf29ce484222325ULL;
+            /* and zlib's CRC-32 (reflected 0xEDB88320) over all bytes read, which the caller can recompute at C speed */
+            uint32_t zcrcTable[256];
+            for ( uint32_t i = 0; i < 256; ++i ) {
+                uint32_t c = i;
+                for ( int k = 0; k < 8; ++k ) c = ( c & 1U ) ? ( c >> 1U ) ^ 0xEDB88320U : ( c >> 1U );
+                zcrcTable[i] = c;
+            }
+            uint32_t zcrc = 0xFFFFFFFFU;
+            size_t total = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for ( const auto at : positions ) {
+                const auto a = std::chrono::steady_clock::now();
+                reader.seek( static_cast<long long>( at ) );
+                const auto n = reader.read( -1, buffer.data(), nBytes );
+                latencies.push_back( std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - a ).count() );
+                for ( size_t i = 0; i < n; ++i ) {
+                    hash ^= static_cast<uint8_t>( buffer[i] );
+                    hash *= 0x100000001b3ULL;
+                    zcrc = zcrcTable[( zcrc ^ static_cast<uint8_t>( buffer[i] ) ) & 0xFFU] ^ ( zcrc >> 8U );
+                }
+                total += n;
+            }
+            const double wall = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+            std::sort( latencies.begin(), latencies.end() );
+            const auto pct = [&] ( double q ) {
+                return latencies.empty() ? 0. : latencies[std::min( latencies.size() - 1, (size_t)( q * latencies.size() ) )];
+            };
+            double mean = 0;
+            for ( const auto v : latencies ) mean += v;
+            mean /= latencies.empty() ? 1 : latencies.size();
+            std::printf( "{\"reads\": %zu, \"read_bytes\": %zu, \"P\": %zu, \"bytes_read\": %zu, \"fnv64\": \"%016llx\", \"zlib_crc32\": %u, "
+                         "\"wall_seconds\": %.4f, \"open_and_import_ms\": %.2f, "
+                         "\"latency_ms\": {\"p50\": %.3f, \"p95\": %.3f, \"p99\": %.3f, \"mean\": %.3f}}\n",
+                         positions.size(), nBytes, P, total, (unsigned long long)hash, zcrc ^ 0xFFFFFFFFU, wall,
+                         std::chrono::duration<double, std::milli>( t0 - tOpen ).count(), pct( 0.50 ), pct( 0.95 ), pct( 0.99 ), mean );
             return 0;
         }
     } catch ( const std::exception& e ) {

@@ -80,9 +80,12 @@ def test_random_pread_with_imported_index(native, silesia_file, exported_index, 
             assert data == raw_slice(base, position, READ_BYTES), position
             assert f.tell() == position + READ_BYTES
         stats = f.statistics()
-        # nothing was decoded to build an index, and random access does not decode the file front to back:
-        # a 64 KiB read touches one or two blocks (more only through what is decoded ahead, which random access turns off)
-        assert stats["blocks_decoded"] < len(offsets) * 3
+        # nothing was decoded to build an index, and random access does not decode the file front to back: a 64 KiB read
+        # touches one or two blocks, and two neighbours in a row look like the start of a sequential read to the access
+        # tracker (as to the reference's FetchNextAdaptive), which then decodes a few blocks ahead: measured 1.3 blocks
+        # per read at parallelization 1, 6.5 at 4
+        print(f"config 5, parallelization {parallelization}: {stats}")
+        assert stats["blocks_decoded"] <= READS * 16
         # the imported index is what the reader reports
         assert f.block_offsets() == exported_index
         # the last bytes and the end of the file

@@ -295,6 +295,32 @@ def test_warmup(native):
         native.warmup(4096, background=False)
 
 
+def test_crc32_of_device_pieces(native, oracle, dec):
+    """mi355x_bz2_crc32_device: bzip2's CRC-32 (bzip2.hpp:59-91, 833, 901) of consecutive pieces of a device buffer --
+    what rank 0 of the bench runs over the extents it receives.  Against the oracle's updateCRC32 on the same bytes, for
+    pieces of awkward sizes (empty, one byte, across the kernel's 64 KiB tiles), and against the block records."""
+    enc, raw = read_fixture("base64-256KiB")
+    offs = oracle.find_magic(enc)
+    dec.set_input(enc)
+    results, total = dec.decode_batch(offs)
+    assert total == len(raw)
+    base = dec.output_device_ptr()
+    # the blocks themselves: the receiver's view of a sender's extent
+    sizes = [r["decoded_size"] for r in results]
+    assert dec.crc32_device(base, sizes) == [r["computed_crc"] for r in results] == [r["header_crc"] for r in results]
+    # arbitrary pieces
+    sizes = [0, 1, 15, 16, 17, 255, 65535, 65536, 65537, 3, 0, 100000]
+    sizes.append(len(raw) - sum(sizes))
+    want, at = [], 0
+    for n in sizes:
+        want.append(oracle.crc32(raw[at:at + n]) ^ 0xFFFFFFFF)
+        at += n
+    assert dec.crc32_device(base, sizes) == want
+    with pytest.raises(native.Bz2Error):
+        dec.crc32_device(base + 4, [16])           # not 16-byte aligned
+    assert dec.crc32_device(base, []) == []
+
+
 @pytest.mark.parametrize("symbols", [1, 2, 15, 16, 17, 127, 128, 129, 255, 256])
 def test_alphabet_sizes_around_the_list_variants(native, oracle, dec, symbols):
     """k_mtf runs in two instances (128-entry and 256-entry lists) chosen by the block's symbol count; 16-entry groups
