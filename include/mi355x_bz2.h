@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI355X_BZ2_ABI_VERSION 1
+#define MI355X_BZ2_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------------ status codes */
 typedef enum mi355x_bz2_status {
@@ -293,6 +293,11 @@ typedef struct mi355x_bz2_reader_stats {
     uint64_t gets, cache_hits, prefetch_hits, on_demand_fetches, prefetches_submitted, batches, blocks_decoded;
     uint64_t failed_prefetches;
     double   decode_seconds, wait_seconds;
+    /* (ABI 2) 1: the whole compressed file is kept on the GPU; 0: bounded residency -- the file does not fit beside the
+     * decoders' scratch, or exceeds MI355X_BZ2_INPUT_BUDGET bytes (environment), and every launch copies the byte range of
+     * its own blocks (the reference streams through 128 KiB refills, src/core/BitReader.hpp:57) */
+    uint64_t input_resident;
+    uint64_t input_bytes_uploaded;   /* bounded residency: compressed bytes copied to the GPU so far, all launches */
 } mi355x_bz2_reader_stats;
 int mi355x_bz2_reader_statistics( const mi355x_bz2_reader* r, mi355x_bz2_reader_stats* stats );
 

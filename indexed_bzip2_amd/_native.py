@@ -76,7 +76,8 @@ class ReaderStats(ctypes.Structure):
                 ("on_demand_fetches", ctypes.c_uint64), ("prefetches_submitted", ctypes.c_uint64),
                 ("batches", ctypes.c_uint64), ("blocks_decoded", ctypes.c_uint64),
                 ("failed_prefetches", ctypes.c_uint64),
-                ("decode_seconds", ctypes.c_double), ("wait_seconds", ctypes.c_double)]
+                ("decode_seconds", ctypes.c_double), ("wait_seconds", ctypes.c_double),
+                ("input_resident", ctypes.c_uint64), ("input_bytes_uploaded", ctypes.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -272,6 +272,7 @@ public:
         if ( m_level == 0 ) {
             fail( MI355X_BZ2_ERR_STREAM_HEADER );
         }
+        m_resident = fitsDevice( device );
         /* Several decoder contexts, each with its own submission thread: while one batch is copied to the host (and
          * consumed), the next ones are being decoded.  They share ONE resident copy of the compressed file.  Only the first
          * context is created here -- the first block goes to it at once; the others are created by their threads, beside
@@ -287,7 +288,9 @@ public:
             std::fprintf( stderr, "[reader] first context, copy of %.0f MB started: %.1f ms\n", m_source->size() / 1e6,
                           std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tCreate ).count() );
         }
-        m_scanner = std::thread( [this] { scanOnDevice(); } );
+        if ( m_resident ) {
+            m_scanner = std::thread( [this] { scanOnDevice(); } );
+        }
         for ( size_t i = 0; i < m_contexts; ++i ) {
             m_workers.emplace_back( [this, i, device] () {
                 if ( i > 0 ) {
@@ -318,8 +321,10 @@ public:
         mi355x_bz2_ctx* ctx = nullptr;
         int rc = mi355x_bz2_create( &config, &ctx );
         if ( rc != MI355X_BZ2_OK ) return rc;
-        rc = shareFrom == nullptr ? mi355x_bz2_set_input_host_streamed( ctx, m_source->bytes(), m_source->size() )
-                                  : mi355x_bz2_share_input( ctx, shareFrom );
+        if ( m_resident ) {
+            rc = shareFrom == nullptr ? mi355x_bz2_set_input_host_streamed( ctx, m_source->bytes(), m_source->size() )
+                                      : mi355x_bz2_share_input( ctx, shareFrom );
+        }   /* else: every launch brings the bytes of its own blocks, see workerMain */
         if ( rc != MI355X_BZ2_OK ) {
             detail = mi355x_bz2_last_error( ctx );
             mi355x_bz2_destroy( ctx );
@@ -328,6 +333,31 @@ public:
         out = ctx;
         return MI355X_BZ2_OK;
     }
+
+    /**
+     * Whether the whole compressed file may be kept resident on the GPU next to the decoders' scratch (the fast way: one
+     * copy, the magic scan on the device).  If not -- a file beyond the free device memory, or beyond
+     * MI355X_BZ2_INPUT_BUDGET bytes -- residency is BOUNDED: every launch copies the byte range of its own blocks into its
+     * context's input buffer (two per context: the next range travels beside the batch in flight), the way the reference
+     * streams a file through 128 KiB refills of its bit reader (src/core/BitReader.hpp:57, filereader/Shared.hpp:238-335);
+     * block offsets then come from the host finder threads alone.
+     */
+    [[nodiscard]] bool
+    fitsDevice( int device ) const
+    {
+        if ( const char* const budget = std::getenv( "MI355X_BZ2_INPUT_BUDGET" ) ) {
+            return m_source->size() <= std::strtoull( budget, nullptr, 10 );
+        }
+        size_t freeBytes = 0, totalBytes = 0;
+        if ( ( device >= 0 && hipSetDevice( device ) != hipSuccess ) || hipMemGetInfo( &freeBytes, &totalBytes ) != hipSuccess ) {
+            return true;    /* no device: creating the first context reports that */
+        }
+        /* scratch and output of every context's batches, and some room for whoever else uses the device */
+        const uint64_t others = (uint64_t)m_contexts * m_batch * ( uint64_t( 15 ) << 20 ) + ( uint64_t( 2 ) << 30 );
+        return m_source->size() + others <= (uint64_t)freeBytes;
+    }
+
+    [[nodiscard]] bool inputResident() const { return m_resident; }
 
     ~BatchScheduler()
     {
@@ -449,6 +479,8 @@ public:
         result.batches = m_batches;
         result.blocks_decoded = m_blocksDecoded;
         result.decode_seconds = m_decodeSeconds;
+        result.input_resident = m_resident ? 1 : 0;
+        result.input_bytes_uploaded = m_uploadedBytes.load( std::memory_order_relaxed );
         return result;
     }
 
@@ -724,7 +756,24 @@ private:
             step.t0 = std::chrono::steady_clock::now();
             const auto n = (uint32_t)step.work->offsets.size();
             step.results.resize( n );
-            int rc = mi355x_bz2_decode_batch_begin( ctx, step.work->offsets.data(), n );
+            int rc = MI355X_BZ2_OK;
+            if ( m_resident ) {
+                rc = mi355x_bz2_decode_batch_begin( ctx, step.work->offsets.data(), n );
+            } else {
+                /* bounded residency: the bytes from the word of the first block's magic to where the last block can end at
+                 * the latest (900 000 symbols of 20 bits and the tables in front of them: below 2 400 000 bytes), and the
+                 * blocks' offsets inside that range.  The copy is queued on the context's input stream; while a batch of
+                 * this context is still being copied out, it lands in the context's second input buffer. */
+                const auto [lowest, highest] = std::minmax_element( step.work->offsets.begin(), step.work->offsets.end() );
+                const uint64_t from = ( *lowest / 8 ) & ~uint64_t( 3 );
+                const uint64_t to = std::min<uint64_t>( m_source->size(), *highest / 8 + 2400000 );
+                std::vector<uint64_t> relative( step.work->offsets );
+                for ( auto& bits : relative ) bits -= 8 * from;
+                rc = from < to ? mi355x_bz2_set_input_host_async( ctx, m_source->bytes() + from, to - from )
+                               : MI355X_BZ2_ERR_INVALID_ARGUMENT;
+                if ( rc == MI355X_BZ2_OK ) rc = mi355x_bz2_decode_batch_begin( ctx, relative.data(), n );
+                m_uploadedBytes.fetch_add( to - from, std::memory_order_relaxed );
+            }
             const auto t1 = std::chrono::steady_clock::now();
             /* while the GPU works: the run in front of this one, and the memory for this one (a block of the usual
              * compressors decodes to at most level x 100 000 bytes; if these decode to more -- later streams of the file
@@ -779,6 +828,8 @@ private:
     size_t m_holdOff{ 0 };
     size_t m_ramp{ 64 };         /* blocks of the next look-ahead launch while the reader is starting up */
     unsigned m_level{ 9 };       /* of the first stream: 100 000 bytes per block and level */
+    bool m_resident{ true };     /* the whole compressed file on the GPU, or the range of every launch (fitsDevice) */
+    std::atomic<uint64_t> m_uploadedBytes{ 0 };
 
     std::vector<mi355x_bz2_ctx*> m_ctxs;
     const std::shared_ptr<PinnedPool> m_hostBuffers{ std::make_shared<PinnedPool>() };

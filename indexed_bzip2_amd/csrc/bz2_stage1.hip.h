@@ -809,51 +809,81 @@ for_symbols( const uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
     }
 }
 
-/** Per-lane write combiner for a sequential byte stream: whole aligned dwords go out as one store (byte-granular
- * scattered stores cost a full write request each: 43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE).  Only the
- * unaligned head and the tail of a lane's range, which share a dword with the neighbouring lane, are written bytewise. */
+/** Per-lane write combiner for a sequential byte stream: whole aligned 16-byte units go out as one store.  Byte-granular
+ * scattered stores cost a full write request each (43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE); dword
+ * stores, round 2's form, still 10.3 GB: the lanes of a wave write 3.5 KB apart, so every store is a partial line of its
+ * own.  Only the unaligned head and the tail of a lane's range, which share a 16-byte unit with the neighbouring lane,
+ * are written bytewise. */
 struct ByteSink
 {
     uint8_t* base;
     uint32_t lo;    /* first byte position of this lane's range */
     uint32_t o;     /* next byte position */
     uint32_t acc;   /* bytes of the dword that contains o, at their place */
+    uint32_t w0, w1, w2;   /* the complete dwords in front of it in the 16-byte unit that contains o */
+
+    __device__ __forceinline__ void
+    bytes_out( uint32_t from, uint32_t to, uint32_t a, uint32_t b, uint32_t c, uint32_t d )
+    {
+        /* bytes [from, to) of the unit that holds them all ({a, b, c, d} = its dwords) */
+        for ( uint32_t k = from; k < to; ++k ) {
+            const uint32_t q = ( k >> 2 ) & 3u;
+            const uint32_t word = q == 0 ? a : ( q == 1 ? b : ( q == 2 ? c : d ) );
+            base[k] = (uint8_t)( word >> ( 8 * ( k & 3u ) ) );
+        }
+    }
+
+    __device__ __forceinline__ void
+    word_done()
+    {
+        /* o is a multiple of 4: `acc` is the dword that ends at o */
+        const uint32_t q = ( ( o - 4 ) >> 2 ) & 3u;
+        if ( q == 3 ) {
+            if ( o - 16 >= lo && o >= 16 ) {
+                *reinterpret_cast<uint4*>( base + o - 16 ) = make_uint4( w0, w1, w2, acc );
+            } else {
+                /* the unit in which the range starts belongs to the previous lane as well */
+                bytes_out( lo, o, w0, w1, w2, acc );
+            }
+            w0 = w1 = w2 = 0;
+        } else {
+            w0 = q == 0 ? acc : w0;
+            w1 = q == 1 ? acc : w1;
+            w2 = q == 2 ? acc : w2;
+        }
+        acc = 0;
+    }
 
     __device__ __forceinline__ void
     put( uint32_t byte )
     {
         acc |= byte << ( 8 * ( o & 3u ) );
         ++o;
-        if ( ( o & 3u ) == 0 ) {
-            if ( o - 4 >= lo ) {
-                *reinterpret_cast<uint32_t*>( base + o - 4 ) = acc;
-            } else {
-                /* the dword in which the range starts belongs to the previous lane as well: bytes */
-                for ( uint32_t k = lo; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
-            }
-            acc = 0;
-        }
+        if ( ( o & 3u ) == 0 ) word_done();
     }
 
     __device__ __forceinline__ void
     fill( uint32_t byte, uint32_t count )
     {
-        while ( count != 0 && ( o & 3u ) != 0 ) { put( byte ); --count; }
+        while ( count != 0 && ( o & 15u ) != 0 ) { put( byte ); --count; }
         const uint32_t word = byte * 0x01010101u;
-        for ( uint32_t k = count >> 2; k != 0; --k ) {
-            *reinterpret_cast<uint32_t*>( base + o ) = word;
-            o += 4;
+        const uint4 unit = make_uint4( word, word, word, word );
+        for ( uint32_t k = count >> 4; k != 0; --k ) {
+            *reinterpret_cast<uint4*>( base + o ) = unit;
+            o += 16;
         }
-        for ( uint32_t k = count & 3u; k != 0; --k ) put( byte );
+        for ( uint32_t k = count & 15u; k != 0; --k ) put( byte );
     }
 
     __device__ __forceinline__ void
     flush()
     {
-        /* the last, incomplete dword (shared with the next lane) */
-        const uint32_t first = ( o & ~3u ) > lo ? ( o & ~3u ) : lo;
-        for ( uint32_t k = first; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
-        acc = 0;
+        /* the last, incomplete unit (shared with the next lane) */
+        const uint32_t unitStart = o & ~15u;
+        const uint32_t first = unitStart > lo ? unitStart : lo;
+        const uint32_t q = ( o >> 2 ) & 3u;     /* the dword `acc` stands for */
+        bytes_out( first, o, q == 0 ? acc : w0, q == 1 ? acc : w1, q == 2 ? acc : w2, acc );
+        acc = w0 = w1 = w2 = 0;
     }
 };
 
@@ -964,7 +994,7 @@ k_mtf( BlockMeta* __restrict__       meta,
         /* positions are 32-bit: a start beyond the buffer (only possible for damaged data, whose runs can add up to
          * anything) is clamped -- that lane then reports the overflow at its first symbol, an earlier lane wins anyway */
         const uint32_t startAt = prefix < MAX_N ? (uint32_t)prefix : MAX_N;
-        ByteSink sink{ L, startAt, startAt, 0 };
+        ByteSink sink{ L, startAt, startAt, 0, 0, 0, 0 };
         uint32_t runPos = 0, hh = 0;
         uint32_t err = 0;
         for_symbols( sym, begin, end, [&] ( uint32_t s ) {

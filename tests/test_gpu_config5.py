@@ -127,6 +127,46 @@ def test_sequential_read_after_warmup_multistream(native, silesia_file, tmp_path
         assert f.read(2000) == raw_slice(base, len(base) * REPEAT - 1000, 2000)
 
 
+@pytest.mark.parametrize("parallelization", [0, 3])
+def test_bounded_residency_of_the_compressed_file(native, silesia_file, exported_index, monkeypatch, parallelization):
+    """A file that may not be kept on the GPU whole (here: MI355X_BZ2_INPUT_BUDGET far below its 85 MB; in production a
+    file beyond the free device memory) is read through all the same: every launch brings the byte range of its own blocks
+    (the reference streams through 128 KiB refills, src/core/BitReader.hpp:57, src/core/filereader/Shared.hpp:238-335).
+    Front to back against the raw bytes, the block map against the resident reader's, then random reads with that map."""
+    import hashlib
+    path, base, enc, offsets = silesia_file
+    monkeypatch.setenv("MI355X_BZ2_INPUT_BUDGET", str(1 << 20))
+    size = len(base) * REPEAT
+    want = hashlib.sha256()
+    for _ in range(REPEAT):
+        want.update(base)
+    got = hashlib.sha256()
+    with native.open(path, parallelization=parallelization) as f:
+        while True:
+            chunk = f.read(32 << 20)
+            if not chunk:
+                break
+            got.update(chunk)
+        assert f.tell() == size and got.digest() == want.digest()
+        assert f.block_offsets() == exported_index
+        stats = f.statistics()
+        assert stats["input_resident"] == 0
+        # every block's bytes went to the GPU once (plus each launch's margin for where its last block may end), not the
+        # whole file per launch
+        assert len(enc) * 0.9 < stats["input_bytes_uploaded"] < len(enc) + stats["batches"] * 2_400_000 + (1 << 20)
+    with native.open(path, parallelization=parallelization) as g:
+        g.set_block_offsets(exported_index)
+        for position in np.random.default_rng(7).integers(0, size - READ_BYTES, 40):
+            position = int(position)
+            g.seek(position)
+            assert g.read(READ_BYTES) == raw_slice(base, position, READ_BYTES), position
+        assert g.statistics()["input_resident"] == 0
+    monkeypatch.delenv("MI355X_BZ2_INPUT_BUDGET")
+    with native.open(path, parallelization=parallelization) as h:
+        assert h.read(1000) == base[:1000]
+        assert h.statistics()["input_resident"] == 1
+
+
 def test_libbz2_agrees_on_a_slice(silesia_file):
     """The stitched file is a valid single stream: CPython's bz2 (libbz2) decodes its head to the raw bytes."""
     path, base, enc, offsets = silesia_file

@@ -309,7 +309,7 @@ def test_crc32_of_device_pieces(native, oracle, dec):
     sizes = [r["decoded_size"] for r in results]
     assert dec.crc32_device(base, sizes) == [r["computed_crc"] for r in results] == [r["header_crc"] for r in results]
     # arbitrary pieces
-    sizes = [0, 1, 15, 16, 17, 255, 65535, 65536, 65537, 3, 0, 100000]
+    sizes = [0, 1, 15, 16, 17, 255, 65535, 65536, 65537, 3, 0, 10000]
     sizes.append(len(raw) - sum(sizes))
     want, at = [], 0
     for n in sizes:

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(native):
     L = native.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.mi355x_bz2_abi_version() == 1
+    assert L.mi355x_bz2_abi_version() == 2
     assert native.status_string(0) == "OK" and "CRC" in native.status_string(15)
 
 

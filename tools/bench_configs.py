@@ -133,30 +133,44 @@ def config5(out):
     # zlib's CRC-32 over all bytes read, in read order: `ref_bz2 pread` prints the same for the reference's reads
     import zlib
     digests = {}
-    for P in (1, 4, 0):
-        with m.open(path, parallelization=P) as g:
-            g.set_block_offsets(index)
+    from indexed_bzip2_amd.reader import IndexedBzip2FileRaw
+    # "raw": seek + read of exactly 64 KiB through the C ABI reader (IndexedBzip2FileRaw), which is what the reference's C++
+    # harness does; "buffered": through ibz2.open() = io.BufferedReader with the reference's 1 MiB buffer
+    # (indexed_bzip2.pyx:337), which fills its buffer behind every seek, i.e. reads 1 MiB = two or three blocks per request
+    for kind, P in (("raw", 1), ("raw", 4), ("raw", 0), ("buffered", 1), ("buffered", 0)):
+        with (IndexedBzip2FileRaw(path, P) if kind == "raw" else m.open(path, parallelization=P)) as g:
+            reader = g.bz2reader
+            reader.set_block_offsets(index)
             lat = []
             crc = 0
+            buf = bytearray(65536)
             t_all = time.perf_counter()
             for pos in positions:
                 t0 = time.perf_counter()
                 g.seek(int(pos))
-                data = g.read(65536)
+                if kind == "raw":
+                    got = 0
+                    while got < 65536:
+                        n = g.readinto(memoryview(buf)[got:])
+                        assert n > 0
+                        got += n
+                    data = buf
+                else:
+                    data = g.read(65536)
                 lat.append(time.perf_counter() - t0)
                 assert len(data) == 65536
                 crc = zlib.crc32(data, crc)
             wall = time.perf_counter() - t_all
-            st = g.statistics()
-        digests[P] = crc
+            st = reader.statistics()
+        digests[(kind, P)] = crc
         lat = np.array(lat) * 1e3
-        out[f"config5_random_pread_P{P}"] = {
-            "reads": 1000, "read_bytes": 65536, "seed": "0x5EEC", "parallelization": P,
+        out[f"config5_random_pread_{kind}_P{P}"] = {
+            "reads": 1000, "read_bytes": 65536, "seed": "0x5EEC", "parallelization": P, "through": kind,
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "p95": round(float(np.percentile(lat, 95)), 3),
                            "p99": round(float(np.percentile(lat, 99)), 3), "mean": round(float(lat.mean()), 3)},
             "MBps_of_requested_bytes": round(1000 * 65536 / wall / 1e6, 2),
-            "blocks_decoded": st["blocks_decoded"], "gpu_batches": st["batches"], "zlib_crc32_of_all_reads": digests[P]}
-        log("config5", out[f"config5_random_pread_P{P}"])
+            "blocks_decoded": st["blocks_decoded"], "gpu_batches": st["batches"], "zlib_crc32_of_all_reads": crc}
+        log("config5", out[f"config5_random_pread_{kind}_P{P}"])
     assert len(set(digests.values())) == 1, "the three parallelizations read different bytes"
     if os.path.exists(REF):
         ref = {}
