@@ -33,6 +33,8 @@ using namespace bz2gpu;
 constexpr uint32_t MAX_CHUNKS = 3;          /* groups of cheap blocks; one more stream than hardware queues (4 by
                                                default) would serialize two groups */
 constexpr int MAX_GROUPS = MAX_CHUNKS + 1;   /* + the expensive group */
+/* default register budgets of the kernels that would otherwise take 160 to 172 registers per lane (MI355X_BZ2_REGS) */
+constexpr uint32_t REGS_SCAN = 4, REGS_SYM = 256 /* groups per k_hsym workgroup */, REGS_MTF = 4, REGS_LINK = 4;
 
 /** A host -> HBM copy of the input that runs in pieces on a thread and a stream of its own
  * (mi355x_bz2_set_input_host_streamed): a batch only waits for the piece in which its last block ends.  Shared by the
@@ -444,6 +446,29 @@ WalkChain& walkChainOf( int device ) { return g_walkChains[(unsigned)device % 16
         HIP_TRY( ctx, hipEventRecord( ( ctx )->ev[group][2 * ( index ) + 1], queue ) );    \
     } while ( 0 )
 
+namespace
+{
+/** Kernels whose LDS is declared at launch (see k_hscan) and exceeds the 64 KB a launch may ask for by default. */
+bool
+allowLargeLds()
+{
+    bool ok = true;
+    const auto allow = [&ok] ( const void* kernel, size_t bytes ) {
+        ok = ok && hipFuncSetAttribute( kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes ) == hipSuccess;
+    };
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, 2> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, 3> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, 4> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, 512> ), sizeof( MtfShared<MTF_LANE_STRIDE, 512> ) );
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_SMALL_STRIDE, 512> ), sizeof( MtfShared<MTF_SMALL_STRIDE, 512> ) );
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_SMALL_STRIDE, 1024> ), sizeof( MtfShared<MTF_SMALL_STRIDE, 1024> ) );
+    allow( reinterpret_cast<const void*>( &k_hsym<512> ), sizeof( SymShared<512> ) );
+    allow( reinterpret_cast<const void*>( &k_link2<2> ), sizeof( LinkShared ) );
+    allow( reinterpret_cast<const void*>( &k_link2<4> ), sizeof( LinkShared ) );
+    return ok;
+}
+}  // namespace
+
 extern "C" {
 
 const char*
@@ -527,6 +552,17 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
     if ( hipGetDeviceProperties( &prop, device ) != hipSuccess ) return MI355X_BZ2_ERR_NO_DEVICE;
     if ( std::strncmp( prop.gcnArchName, "gfx950", 6 ) != 0 ) {
         return MI355X_BZ2_ERR_NO_DEVICE;   /* kernels are built for gfx950 only */
+    }
+    if ( hipSetDevice( device ) != hipSuccess ) return MI355X_BZ2_ERR_DEVICE;
+    {
+        /* once per device (the attribute belongs to the kernel's image on a device) */
+        static std::mutex once;
+        static bool done[16] = {};
+        const std::scoped_lock lock( once );
+        if ( !done[(unsigned)device % 16u] ) {
+            if ( !allowLargeLds() ) return MI355X_BZ2_ERR_DEVICE;
+            done[(unsigned)device % 16u] = true;
+        }
     }
     auto* c = new mi355x_bz2_ctx();
     c->device = device;
@@ -1069,6 +1105,27 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
     const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
     const uint32_t scanGrid = sg != nullptr ? (uint32_t)std::atoi( sg ) : 0u;
+    /* register budgets (wavefronts per SIMD that a kernel's registers leave room for, see k_hscan):
+     * MI355X_BZ2_REGS="scan=4,sym=4,mtf=4,link=4"; 2 = what the compiler takes when it is only told the kernel's own LDS */
+    struct { uint32_t scan, sym, mtf, link; } regs = { REGS_SCAN, REGS_SYM, REGS_MTF, REGS_LINK };
+    if ( const char* text = std::getenv( "MI355X_BZ2_REGS" ) ) {
+        const auto value = [text] ( const char* key, uint32_t otherwise ) {
+            const char* at = std::strstr( text, key );
+            return at != nullptr && at[std::strlen( key )] == '=' ? (uint32_t)std::atoi( at + std::strlen( key ) + 1 ) : otherwise;
+        };
+        regs.scan = value( "scan", regs.scan );
+        regs.sym = value( "sym", regs.sym );
+        regs.mtf = value( "mtf", regs.mtf );
+        regs.link = value( "link", regs.link );
+    }
+    /* Walk segments per block.  Many short ones (KMAX = 32 768 of 27 bytes) make a lone block's walk short; a batch that
+     * fills the GPU anyway is better off with a quarter of them, four times as long: per-segment work (queue, records,
+     * k_link2's chain of 32 768 successors per block, k_emit's records) shrinks by four, the stash (512 instead of 128 bytes
+     * per segment) holds 99 % of the bytes either way.  MI355X_BZ2_SEGMENTS=long|short forces one. */
+    bool longSegments = false;   /* measured slower for the bench's batch (k_link2 4.7 -> 1.8 ms, but k_walk 21 -> 32, k_emit 5.3 -> 10.8) */
+    if ( const char* sg2 = std::getenv( "MI355X_BZ2_SEGMENTS" ) ) longSegments = sg2[0] == 'l';
+    const uint32_t segTarget = longSegments ? KMAX / 4 : KMAX;
+    const uint32_t stashBytes = longSegments ? STASH_BYTES_LONG : STASH_BYTES;
     const char* smx = std::getenv( "MI355X_BZ2_SCAN_MIXED" );   /* 0: off; 4 / 8: that many waves per expensive block; default: by count */
     const uint32_t scanMixed = smx != nullptr ? (uint32_t)std::atoi( smx ) : 1u;
     const char* wsr = std::getenv( "MI355X_BZ2_WALK_SERIAL" );
@@ -1130,34 +1187,54 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<4>, dim3( m ), dim3( 256 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
             } else if ( scanWaves >= 8 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), sizeof( ScanShared<8> ), q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             } else if ( scanWaves >= 4 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), 0, q, inWords, inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), sizeof( ScanShared<4> ), q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             } else if ( scanWaves >= 2 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
+                TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), sizeof( ScanShared<2> ), q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
             } else if ( scanPc ) {
                 /* one block per workgroup, producer + consumer wave (k_hscan_pc) */
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_pc, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order );
-            } else if ( scanGrid != 0 && scanGrid < m ) {
-                HIP_TRY( c, hipMemsetAsync( c->dScanQueue + g, 0, sizeof( uint32_t ), q ) );
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( scanGrid ), dim3( 64 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, c->dScanQueue + g );
             } else {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<1>, dim3( m ), dim3( 64 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
+                uint32_t* scanQueue = nullptr;
+                uint32_t grid = m;
+                if ( scanGrid != 0 && scanGrid < m ) {
+                    HIP_TRY( c, hipMemsetAsync( c->dScanQueue + g, 0, sizeof( uint32_t ), q ) );
+                    scanQueue = c->dScanQueue + g;
+                    grid = scanGrid;
+                }
+#define SCAN1( W ) TIMED_LAUNCH( c, g, q, 12, ( k_hscan<1, W> ), dim3( grid ), dim3( 64 ), sizeof( ScanShared<1> ), q, inWords, inSize, \
+                                 c->dOffsets + first, meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, scanQueue )
+                if ( regs.scan >= 5 ) { SCAN1( 5 ); } else if ( regs.scan == 4 ) { SCAN1( 4 ); } else { SCAN1( 2 ); }
+#undef SCAN1
             }
-            TIMED_LAUNCH( c, g, q, 13, k_hsym, dim3( ( MAX_SCAN_GROUPS + SYM_THREADS - 1 ) / SYM_THREADS, m ), dim3( SYM_THREADS ),
-                          0, q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym );
+#define HSYM( T ) TIMED_LAUNCH( c, g, q, 13, k_hsym<T>, dim3( ( MAX_SCAN_GROUPS + ( T ) - 1 ) / ( T ), m ), dim3( T ), \
+                                sizeof( SymShared<T> ), q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym )
+            if ( regs.sym >= 512 ) { HSYM( 512 ); } else if ( regs.sym >= 256 ) { HSYM( 256 ); } else { HSYM( 128 ); }
+#undef HSYM
         } else {
             const uint32_t huffGrid = std::min( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES, g == expensiveGroup ? huffCapExpensive : huffCap );
             TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
                           reinterpret_cast<const uint32_t*>( inBase ), inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
                           m, order );
         }
+#define MTF256( STRIDE, STREAM, INDEX ) \
+        do { \
+            if ( regs.mtf >= 4 ) { \
+                TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, 4> ), dim3( m ), dim3( MTF_THREADS ), \
+                              sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order, segTarget ); \
+            } else if ( regs.mtf == 3 ) { \
+                TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, 3> ), dim3( m ), dim3( MTF_THREADS ), \
+                              sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order, segTarget ); \
+            } else { \
+                TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, 2> ), dim3( m ), dim3( MTF_THREADS ), \
+                              sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order, segTarget ); \
+            } \
+        } while ( 0 )
         /* Every block belongs to one of the two k_mtf instances (by its symbol count), the other returns at once.  In a
          * small batch each lasts as long as its slowest block (4 and 7 ms): side by side instead of one behind the other. */
         if ( n <= 1280 ) {
@@ -1174,41 +1251,61 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                 /* few blocks: 512 lanes per block, each with half the symbols */
                 if ( n <= 64 ) {
                     /* (the 128-entry lists of 1 024 lanes still fit the LDS of a CU: 152 KB) */
-                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 1024> ), dim3( m ), dim3( 1024 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 1024> ), dim3( m ), dim3( 1024 ), sizeof( MtfShared<MTF_SMALL_STRIDE, 1024> ), side, meta, hmeta, sym, stb, lcol, m, order, segTarget );
                 } else {
-                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), sizeof( MtfShared<MTF_SMALL_STRIDE, 512> ), side, meta, hmeta, sym, stb, lcol, m, order, segTarget );
                 }
                 HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
-                TIMED_LAUNCH( c, g, q, 1, ( k_mtf<MTF_LANE_STRIDE, 512> ), dim3( m ), dim3( 512 ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+                TIMED_LAUNCH( c, g, q, 1, ( k_mtf<MTF_LANE_STRIDE, 512> ), dim3( m ), dim3( 512 ), sizeof( MtfShared<MTF_LANE_STRIDE, 512> ), q, meta, hmeta, sym, stb, lcol, m, order, segTarget );
             } else {
-                TIMED_LAUNCH( c, g, side, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, side, meta, hmeta, sym, stb, lcol, m, order );
+                MTF256( MTF_SMALL_STRIDE, side, 11 );
                 HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
-                TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+                MTF256( MTF_LANE_STRIDE, q, 1 );
             }
             HIP_TRY( c, hipStreamWaitEvent( q, c->evJoin[g], 0 ) );
         } else {
-            TIMED_LAUNCH( c, g, q, 11, k_mtf<MTF_SMALL_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
-            TIMED_LAUNCH( c, g, q, 1, k_mtf<MTF_LANE_STRIDE>, dim3( m ), dim3( MTF_THREADS ), 0, q, meta, hmeta, sym, stb, lcol, m, order );
+            MTF256( MTF_SMALL_STRIDE, q, 11 );
+            MTF256( MTF_LANE_STRIDE, q, 1 );
         }
+#undef MTF256
         TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
         if ( walkSerial ) {
             WalkChain& walks = walkChainOf( c->device );
             const std::scoped_lock chain( walks.mutex );
             if ( walks.last != nullptr ) HIP_TRY( c, hipStreamWaitEvent( q, walks.last, 0 ) );
-            TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
-                          meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            if ( longSegments ) {
+                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES_LONG>, walkGrid, dim3( WALK_THREADS ), 0, q,
+                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            } else {
+                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES>, walkGrid, dim3( WALK_THREADS ), 0, q,
+                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            }
             hipEvent_t& slot = walks.events[walks.next++ % 64];
             if ( slot == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &slot, hipEventDisableTiming ) );
             HIP_TRY( c, hipEventRecord( slot, q ) );
             walks.last = slot;
         } else {
-            TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
-                          meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            if ( longSegments ) {
+                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES_LONG>, walkGrid, dim3( WALK_THREADS ), 0, q,
+                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            } else {
+                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES>, walkGrid, dim3( WALK_THREADS ), 0, q,
+                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
+            }
         }
-        TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), 0, q, meta, segLen, segSucc, segCont, segOff, chain );
-        TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
-                      meta, tab, chain, stash, rbuf );
+        if ( regs.link >= 4 ) {
+            TIMED_LAUNCH( c, g, q, 4, k_link2<4>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, segOff, chain, stashBytes );
+        } else {
+            TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, segOff, chain, stashBytes );
+        }
+        if ( longSegments ) {
+            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES_LONG>, dim3( ( KMAX / 4 + 2 + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
+                          meta, tab, chain, stash, rbuf );
+        } else {
+            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES>, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
+                          meta, tab, chain, stash, rbuf );
+        }
         TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, lcol );
         TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );
         if ( g >= 1 ) {

@@ -687,8 +687,13 @@ scan_build_rows( uint32_t rw, bool nearEnd, ScanSlot& slot, const uint8_t* lenlu
 #undef SCAN_CASE
 }
 
-template<uint32_t K>
-__global__ __launch_bounds__( 64 * K ) void
+/* W = wavefronts per SIMD that the kernel's registers must leave room for.  Its LDS alone allows 2.5 per SIMD, and the
+ * compiler, seeing that, spends 172 registers per lane: fine for this kernel by itself, but two such waves on a SIMD leave
+ * no room for ONE wave of k_mtf or k_link2 (169 to 171 registers) of the batches beside it, and only 2 048 of a big batch's
+ * 2 560 blocks are resident at a time.  The LDS is therefore declared at launch (the compiler does not see its size) and
+ * the register budget is given: W = 4 -> 128 registers (7 spilled, none in the chase), W = 5 -> 96. */
+template<uint32_t K, uint32_t W = 2>
+__global__ __launch_bounds__( 64 * K ) __attribute__( ( amdgpu_waves_per_eu( W, 8 ) ) ) void
 k_hscan( const uint32_t* __restrict__ in_words,
          uint64_t                     in_size_bytes,
          const uint64_t* __restrict__ offsets,
@@ -706,7 +711,8 @@ k_hscan( const uint32_t* __restrict__ in_words,
                                                   the host) until none is left, so that a grid smaller than the batch -- one
                                                   that leaves LDS to the kernels of other streams -- still decodes all of it */
 {
-    __shared__ ScanShared<K> sh;
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( ScanShared<K> ) */
+    ScanShared<K>& sh = *reinterpret_cast<ScanShared<K>*>( ldsAtLaunch );
     for ( uint32_t slotIndex = blockIdx.x;; slotIndex += gridDim.x ) {
     if ( K == 1 && queue != nullptr ) {
         uint32_t taken = 0;
@@ -1530,13 +1536,17 @@ k_hscan_pc( const uint32_t* __restrict__ in_words,
 
 /* ============================================================================================================= */
 
+template<uint32_t THREADS>
 struct alignas( 16 ) SymShared
 {
     HuffTables tabs;
-    uint16_t stage[SYM_THREADS * GROUP_SYMS];
+    uint16_t stage[THREADS * GROUP_SYMS];
 };
 
-__global__ __launch_bounds__( SYM_THREADS ) void
+/* THREADS = groups per workgroup: the block's tables (17 KB) are loaded once per workgroup.  LDS declared at launch, see
+ * k_hscan: the compiler then takes the 26 registers the kernel needs instead of the 129 that its LDS-bound occupancy allows. */
+template<uint32_t THREADS = SYM_THREADS>
+__global__ __launch_bounds__( THREADS ) void
 k_hsym( const uint32_t* __restrict__   in_words,
         BlockMeta* __restrict__        meta,
         HuffMeta* __restrict__         hmeta,
@@ -1546,16 +1556,17 @@ k_hsym( const uint32_t* __restrict__   in_words,
         const uint32_t* __restrict__   gpos_buf,
         uint16_t* __restrict__         sym_buf )
 {
-    __shared__ SymShared sh;
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( SymShared<THREADS> ) */
+    SymShared<THREADS>& sh = *reinterpret_cast<SymShared<THREADS>*>( ldsAtLaunch );
     const uint32_t b = blockIdx.y;
     const ScanMeta sm = smeta[b];
-    const uint32_t g0 = blockIdx.x * SYM_THREADS;
+    const uint32_t g0 = blockIdx.x * THREADS;
     if ( g0 >= sm.n_groups ) return;
     const uint32_t tid = threadIdx.x;
     {
         const uint4* const src = reinterpret_cast<const uint4*>( tab_buf + b );
         uint4* const dst = reinterpret_cast<uint4*>( &sh.tabs );
-        for ( uint32_t k = tid; k < sizeof( HuffTables ) / 16; k += SYM_THREADS ) dst[k] = src[k];
+        for ( uint32_t k = tid; k < sizeof( HuffTables ) / 16; k += THREADS ) dst[k] = src[k];
     }
     __syncthreads();
 
@@ -1631,11 +1642,11 @@ k_hsym( const uint32_t* __restrict__   in_words,
     __syncthreads();
     /* stage -> memory: the groups of a workgroup are one contiguous piece of the symbol buffer */
     {
-        const uint32_t nHere = sm.n_groups - g0 < SYM_THREADS ? sm.n_groups - g0 : SYM_THREADS;
+        const uint32_t nHere = sm.n_groups - g0 < THREADS ? sm.n_groups - g0 : THREADS;
         const uint32_t units = ( nHere * GROUP_SYMS * 2 + 15 ) / 16;   /* the symbol buffer is padded */
         uint4* const dst = reinterpret_cast<uint4*>( sym_buf + (size_t)b * SYM_STRIDE + (size_t)g0 * GROUP_SYMS );
         const uint4* const src = reinterpret_cast<const uint4*>( sh.stage );
-        for ( uint32_t k = tid; k < units; k += SYM_THREADS ) dst[k] = src[k];
+        for ( uint32_t k = tid; k < units; k += THREADS ) dst[k] = src[k];
     }
 }
 }  // namespace bz2gpu

@@ -809,47 +809,33 @@ for_symbols( const uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
     }
 }
 
-/** Per-lane write combiner for a sequential byte stream: whole aligned 16-byte units go out as one store.  Byte-granular
- * scattered stores cost a full write request each (43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE); dword
- * stores, round 2's form, still 10.3 GB: the lanes of a wave write 3.5 KB apart, so every store is a partial line of its
- * own.  Only the unaligned head and the tail of a lane's range, which share a 16-byte unit with the neighbouring lane,
- * are written bytewise. */
+/** Per-lane write combiner for a sequential byte stream: whole aligned dwords go out as one store (byte-granular
+ * scattered stores cost a full write request each: 43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE).  Only the
+ * unaligned head and the tail of a lane's range, which share a dword with the neighbouring lane, are written bytewise.
+ * Runs are what this is tuned for: half the symbols of a text block are run digits, most runs are shorter than a dword, and
+ * with a loop of single bytes per run the expansion was a third of k_mtf (3.7 of 11 ms per instance for the bench's batch,
+ * profiles/r03_mtf_probe.txt): fill() completes the current dword and starts the last one with two masked ORs, its only loop is over
+ * the whole dwords of a long run.
+ * (Round 3 also tried whole 16-byte units per store -- three more registers for the dwords in front of the current one, a
+ * select per completed dword: the L column's write traffic falls, but k_mtf took 14.5 instead of 8.9 ms (<144>) and 14.5
+ * instead of 10.4 ms (<272>) for the bench's batch, the step 73 instead of 66 ms.  With the stores folded into a window of
+ * 256 bytes per lane the kernel is as slow as with the real addresses: it is not the write traffic that bounds it.) */
 struct ByteSink
 {
     uint8_t* base;
     uint32_t lo;    /* first byte position of this lane's range */
     uint32_t o;     /* next byte position */
     uint32_t acc;   /* bytes of the dword that contains o, at their place */
-    uint32_t w0, w1, w2;   /* the complete dwords in front of it in the 16-byte unit that contains o */
-
-    __device__ __forceinline__ void
-    bytes_out( uint32_t from, uint32_t to, uint32_t a, uint32_t b, uint32_t c, uint32_t d )
-    {
-        /* bytes [from, to) of the unit that holds them all ({a, b, c, d} = its dwords) */
-        for ( uint32_t k = from; k < to; ++k ) {
-            const uint32_t q = ( k >> 2 ) & 3u;
-            const uint32_t word = q == 0 ? a : ( q == 1 ? b : ( q == 2 ? c : d ) );
-            base[k] = (uint8_t)( word >> ( 8 * ( k & 3u ) ) );
-        }
-    }
 
     __device__ __forceinline__ void
     word_done()
     {
-        /* o is a multiple of 4: `acc` is the dword that ends at o */
-        const uint32_t q = ( ( o - 4 ) >> 2 ) & 3u;
-        if ( q == 3 ) {
-            if ( o - 16 >= lo && o >= 16 ) {
-                *reinterpret_cast<uint4*>( base + o - 16 ) = make_uint4( w0, w1, w2, acc );
-            } else {
-                /* the unit in which the range starts belongs to the previous lane as well */
-                bytes_out( lo, o, w0, w1, w2, acc );
-            }
-            w0 = w1 = w2 = 0;
+        /* o is a multiple of 4: `acc` is the dword that ends there */
+        if ( o - 4 >= lo ) {
+            *reinterpret_cast<uint32_t*>( base + o - 4 ) = acc;
         } else {
-            w0 = q == 0 ? acc : w0;
-            w1 = q == 1 ? acc : w1;
-            w2 = q == 2 ? acc : w2;
+            /* the dword in which the range starts belongs to the previous lane as well: bytes */
+            for ( uint32_t k = lo; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
         }
         acc = 0;
     }
@@ -865,25 +851,33 @@ struct ByteSink
     __device__ __forceinline__ void
     fill( uint32_t byte, uint32_t count )
     {
-        while ( count != 0 && ( o & 15u ) != 0 ) { put( byte ); --count; }
         const uint32_t word = byte * 0x01010101u;
-        const uint4 unit = make_uint4( word, word, word, word );
-        for ( uint32_t k = count >> 4; k != 0; --k ) {
-            *reinterpret_cast<uint4*>( base + o ) = unit;
-            o += 16;
+        const uint32_t n = o & 3u;
+        if ( n != 0 ) {
+            /* the rest of the current dword, or as much of it as the run has: 1 to 3 bytes */
+            const uint32_t take = count < 4 - n ? count : 4 - n;
+            acc |= ( word & ( ( 1u << ( 8 * take ) ) - 1u ) ) << ( 8 * n );
+            o += take;
+            count -= take;
+            if ( ( o & 3u ) == 0 ) word_done();
         }
-        for ( uint32_t k = count & 15u; k != 0; --k ) put( byte );
+        /* (whatever is left starts a dword) */
+        for ( uint32_t k = count >> 2; k != 0; --k ) {
+            *reinterpret_cast<uint32_t*>( base + o ) = word;
+            o += 4;
+        }
+        const uint32_t rest = count & 3u;
+        acc |= word & ( ( 1u << ( 8 * rest ) ) - 1u );
+        o += rest;
     }
 
     __device__ __forceinline__ void
     flush()
     {
-        /* the last, incomplete unit (shared with the next lane) */
-        const uint32_t unitStart = o & ~15u;
-        const uint32_t first = unitStart > lo ? unitStart : lo;
-        const uint32_t q = ( o >> 2 ) & 3u;     /* the dword `acc` stands for */
-        bytes_out( first, o, q == 0 ? acc : w0, q == 1 ? acc : w1, q == 2 ? acc : w2, acc );
-        acc = w0 = w1 = w2 = 0;
+        /* the last, incomplete dword (shared with the next lane) */
+        const uint32_t first = ( o & ~3u ) > lo ? ( o & ~3u ) : lo;
+        for ( uint32_t k = first; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
+        acc = 0;
     }
 };
 
@@ -894,23 +888,38 @@ struct ByteSink
  * workgroups share a CU instead of two -- the kernel is bound by instruction issue at two waves per SIMD.  Both are
  * launched over all blocks, a workgroup whose block belongs to the other instance returns at once.  Both strides keep
  * the 16-byte accesses of 16 lanes on 64 distinct banks (stride / 4 mod 64 is an odd multiple of 4). */
-template<uint32_t LANE_STRIDE, uint32_t THREADS = MTF_THREADS>
-__global__ __launch_bounds__( THREADS ) void
-k_mtf( BlockMeta* __restrict__       meta,
-       const HuffMeta* __restrict__  hmeta,
-       const uint16_t* __restrict__  sym_buf,
-       const uint8_t* __restrict__   stb_buf,
-       uint8_t* __restrict__         l_buf,
-       uint32_t                      n_blocks,
-       const uint32_t* __restrict__  order )
+template<uint32_t LANE_STRIDE, uint32_t THREADS>
+struct alignas( 16 ) MtfShared
+{
+    uint8_t listBytes[THREADS * LANE_STRIDE];   /* 68 / 36 KiB with 256 lanes */
+    uint4 permRows[16];
+    uint8_t cur[256];
+    uint32_t starts[THREADS + 1];
+    unsigned long long waveTotals[THREADS / 64];
+    uint32_t firstError;
+};
+
+/* The body of k_mtf.  Its LDS arrays arrive as __restrict__ parameters: they are pieces of ONE launch-time allocation (see
+ * k_mtf), and as plain pointers into it they could alias each other for all the compiler knows. */
+template<uint32_t LANE_STRIDE, uint32_t THREADS>
+__device__ __forceinline__ void
+mtf_block( BlockMeta* __restrict__       meta,
+           const HuffMeta* __restrict__  hmeta,
+           const uint16_t* __restrict__  sym_buf,
+           const uint8_t* __restrict__   stb_buf,
+           uint8_t* __restrict__         l_buf,
+           uint32_t                      n_blocks,
+           const uint32_t* __restrict__  order,
+           uint32_t                      seg_target,
+           uint8_t* __restrict__         listBytes,
+           uint4* __restrict__           permRows,
+           uint8_t* __restrict__         cur,
+           uint32_t* __restrict__        starts,
+           unsigned long long* __restrict__ waveTotals,
+           uint32_t* __restrict__        firstErrorAt )
 {
     constexpr uint32_t LIST_ENTRIES = LANE_STRIDE - 16;
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t listBytes[THREADS * LANE_STRIDE];   /* 68 / 36 KiB with 256 lanes */
-    __shared__ uint4 permRows[16];
-    __shared__ uint8_t cur[256];
-    __shared__ uint32_t starts[THREADS + 1];
-    __shared__ unsigned long long waveTotals[THREADS / 64];
-    __shared__ uint32_t firstError;
+    uint32_t& firstError = *firstErrorAt;
 
     const uint32_t slot = blockIdx.x;
     if ( slot >= n_blocks ) return;
@@ -989,12 +998,14 @@ k_mtf( BlockMeta* __restrict__       meta,
         __syncthreads();
     }
 
-    /* ---- pass B: replay with the true start list, write the L column ---- */
+    /* ---- pass B: replay with the true start list, write the L column.  (Round 3 measured the alternative -- pass A replaces
+     * every symbol by the position its entry has in the chunk's start list, pass B only looks positions up: the list updates
+     * of a pass cost 0.1 to 1.4 ms of its 3.3 ms, the rewritten symbols 4.6 GB of writes; no gain, profiles/r03_mtf_probe.txt) ---- */
     {
         /* positions are 32-bit: a start beyond the buffer (only possible for damaged data, whose runs can add up to
          * anything) is clamped -- that lane then reports the overflow at its first symbol, an earlier lane wins anyway */
         const uint32_t startAt = prefix < MAX_N ? (uint32_t)prefix : MAX_N;
-        ByteSink sink{ L, startAt, startAt, 0, 0, 0, 0 };
+        ByteSink sink{ L, startAt, startAt, 0 };
         uint32_t runPos = 0, hh = 0;
         uint32_t err = 0;
         for_symbols( sym, begin, end, [&] ( uint32_t s ) {
@@ -1035,12 +1046,31 @@ k_mtf( BlockMeta* __restrict__       meta,
         if ( status == ST_OK && origPtr >= N ) status = ST_ORIGPTR_DATA;
         meta[b].n = status == ST_OK || status == ST_ORIGPTR_DATA ? (uint32_t)total : 0u;
         meta[b].status = status;
-        uint32_t stride = ( N + KMAX - 1 ) / KMAX;
+        /* walk segments: about seg_target of them (<= KMAX), a table entry in every `stride` a segment start */
+        uint32_t stride = ( N + seg_target - 1 ) / seg_target;
         if ( stride < MIN_SEG_STRIDE ) stride = MIN_SEG_STRIDE;
         const uint32_t k0 = ( N + stride - 1 ) / stride;
         meta[b].seg_stride = stride;
         meta[b].nseg = k0 + ( ( N > 0 && origPtr % stride != 0 ) ? 1u : 0u );
         meta[b].walk_ok = ( status == ST_OK && N > 0 ) ? 1u : 0u;
     }
+}
+
+/* W: wavefronts per SIMD the registers leave room for, LDS declared at launch -- see k_hscan (bz2_hscan.hip.h). */
+template<uint32_t LANE_STRIDE, uint32_t THREADS = MTF_THREADS, uint32_t W = 2>
+__global__ __launch_bounds__( THREADS ) __attribute__( ( amdgpu_waves_per_eu( W, 8 ) ) ) void
+k_mtf( BlockMeta* __restrict__       meta,
+       const HuffMeta* __restrict__  hmeta,
+       const uint16_t* __restrict__  sym_buf,
+       const uint8_t* __restrict__   stb_buf,
+       uint8_t* __restrict__         l_buf,
+       uint32_t                      n_blocks,
+       const uint32_t* __restrict__  order,
+       uint32_t                      seg_target )   /* walk segments per block to aim for, 1 .. KMAX */
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( MtfShared<LANE_STRIDE, THREADS> ) */
+    auto& shared = *reinterpret_cast<MtfShared<LANE_STRIDE, THREADS>*>( ldsAtLaunch );
+    mtf_block<LANE_STRIDE, THREADS>( meta, hmeta, sym_buf, stb_buf, l_buf, n_blocks, order, seg_target, shared.listBytes, shared.permRows,
+                                     shared.cur, shared.starts, shared.waveTotals, &shared.firstError );
 }
 }  // namespace bz2gpu

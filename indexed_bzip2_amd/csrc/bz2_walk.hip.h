@@ -29,8 +29,11 @@ constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
 constexpr uint32_t WALK_WGS_PER_XCD = 128;    /* one or two contexts */
 constexpr uint32_t WALK_WGS_CROWD = 64;       /* three or more contexts alive: see bz2_device.hip */
 constexpr uint32_t WALK_QUEUES = 8;
-constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps (two 64-B lines per segment: 1 % of the
-                                                bytes lie beyond, 10 % with one line) */
+constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps when a block is cut into KMAX segments of
+                                                27 bytes on average (two 64-B lines per segment: 1 % of the bytes lie beyond,
+                                                10 % with one line); also what the stash buffer holds per segment slot */
+constexpr uint32_t STASH_BYTES_LONG = 512;   /* the same for batches whose blocks are cut into KMAX / 4 segments (108 bytes on
+                                                average, 0.9 % of the bytes beyond): same buffer, a quarter of the slots */
 constexpr uint32_t EMIT_THREADS = 256;       /* segments (consecutive along the cycle) per k_emit workgroup */
 constexpr uint32_t EMIT_STAGE = 16384;       /* LDS bytes that collect their output before it is written in whole lines */
 
@@ -88,20 +91,32 @@ constexpr uint32_t LINK_THREADS = 256;
 constexpr uint32_t LINK_SPLIT = 128;
 constexpr uint32_t LINK_MAX_SUB = KMAX / LINK_SPLIT + 2;   /* 258 */
 
-__global__ __launch_bounds__( LINK_THREADS ) void
-k_link2( BlockMeta*                   meta,
-         const uint32_t* __restrict__ seg_len,
-         const uint32_t* __restrict__ seg_succ,
-         const uint32_t* __restrict__ seg_cont,
-         uint32_t* __restrict__       seg_off,
-         uint4* __restrict__          chain )
+struct alignas( 16 ) LinkShared
 {
-    __shared__ uint16_t ssucc[SEG_STRIDE];          /* 64 KiB */
-    __shared__ uint32_t subLen[LINK_MAX_SUB];       /* bytes covered by sub-chain s */
-    __shared__ uint16_t subNext[LINK_MAX_SUB];      /* sub-chain that follows (index), 0xFFFF if broken */
-    __shared__ uint32_t subOff[LINK_MAX_SUB];       /* output offset of the sub-chain, INVALID_OFF if off the cycle */
-    __shared__ uint32_t subCnt[LINK_MAX_SUB];       /* segments in sub-chain s */
-    __shared__ uint32_t subRank[LINK_MAX_SUB];      /* position of its first segment along the cycle */
+    uint16_t ssucc[SEG_STRIDE];          /* 64 KiB */
+    uint32_t subLen[LINK_MAX_SUB];       /* bytes covered by sub-chain s */
+    uint16_t subNext[LINK_MAX_SUB];      /* sub-chain that follows (index), 0xFFFF if broken */
+    uint32_t subOff[LINK_MAX_SUB];       /* output offset of the sub-chain, INVALID_OFF if off the cycle */
+    uint32_t subCnt[LINK_MAX_SUB];       /* segments in sub-chain s */
+    uint32_t subRank[LINK_MAX_SUB];      /* position of its first segment along the cycle */
+};
+
+/* The body of k_link2; its LDS arrays as __restrict__ parameters (pieces of one launch-time allocation, see k_mtf). */
+__device__ __forceinline__ void
+link_block( BlockMeta*                   meta,
+            const uint32_t* __restrict__ seg_len,
+            const uint32_t* __restrict__ seg_succ,
+            const uint32_t* __restrict__ seg_cont,
+            uint32_t* __restrict__       seg_off,
+            uint4* __restrict__          chain,
+            uint32_t                     stash_bytes,
+            uint16_t* __restrict__       ssucc,
+            uint32_t* __restrict__       subLen,
+            uint16_t* __restrict__       subNext,
+            uint32_t* __restrict__       subOff,
+            uint32_t* __restrict__       subCnt,
+            uint32_t* __restrict__       subRank )
+{
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok ) return;
@@ -180,8 +195,8 @@ k_link2( BlockMeta*                   meta,
             const uint32_t len = seg_len[base + cur];
             seg_off[base + cur] = off;
             /* record for k_emit, in cycle order: segment, output offset, length, where its walk goes on after the
-             * STASH_BYTES the first pass kept */
-            chain[base + rank] = make_uint4( cur, off, len, len > STASH_BYTES ? seg_cont[base + cur] : 0u );
+             * stash_bytes the first pass kept */
+            chain[base + rank] = make_uint4( cur, off, len, len > stash_bytes ? seg_cont[base + cur] : 0u );
             ++rank;
             off += len;
             cur = ssucc[cur];
@@ -191,6 +206,31 @@ k_link2( BlockMeta*                   meta,
     }
 }
 
+/* W: wavefronts per SIMD the registers leave room for, LDS declared at launch -- see k_hscan (bz2_hscan.hip.h). */
+template<uint32_t W = 2>
+__global__ __launch_bounds__( LINK_THREADS ) __attribute__( ( amdgpu_waves_per_eu( W, 8 ) ) ) void
+k_link2( BlockMeta*                   meta,
+         const uint32_t* __restrict__ seg_len,
+         const uint32_t* __restrict__ seg_succ,
+         const uint32_t* __restrict__ seg_cont,
+         uint32_t* __restrict__       seg_off,
+         uint4* __restrict__          chain,
+         uint32_t                     stash_bytes )   /* what k_walk kept of every segment */
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( LinkShared ) */
+    auto& shared = *reinterpret_cast<LinkShared*>( ldsAtLaunch );
+    link_block( meta, seg_len, seg_succ, seg_cont, seg_off, chain, stash_bytes, shared.ssucc, shared.subLen, shared.subNext, shared.subOff,
+                shared.subCnt, shared.subRank );
+}
+
+/* The walk of the segments.  A lane follows ONE segment at a time, sixteen steps (one 16-byte piece of the segment's stash)
+ * per round, and takes its next segment at the end of the round in which it finished one.  (Up to round 2 the lanes of a
+ * wave took their next segments together, when the longest of them was through: segment lengths are geometric -- mean 27,
+ * the longest of 64 about 128 --, so 22 % of the lanes of a gather instruction were alive, PMC: 10.6 G lane slots for 2.3 G
+ * steps; the walk is bound by the latency of its dependent gathers, i.e. by how many of them are in flight.)  Within a claim
+ * of `chunk` segments the runs that belong to one block are handled one after the other, so that everything a lane needs to
+ * start a segment is uniform: its number, the stride, and one table look-up. */
+template<uint32_t STASH = STASH_BYTES>
 __global__ __launch_bounds__( WALK_THREADS ) void
 k_walk( const BlockMeta* __restrict__ meta,
          const uint32_t* __restrict__  tab_buf,
@@ -200,11 +240,12 @@ k_walk( const BlockMeta* __restrict__ meta,
          uint32_t*                     seg_len,
          uint32_t*                     seg_succ,
          uint32_t                      chunk,
-         uint32_t*                     stash,      /* [block][segment][STASH_BYTES / 4] */
-         uint32_t*                     seg_cont )  /* table index of byte STASH_BYTES of a longer segment */
+         uint32_t*                     stash,      /* [block][SEG_STRIDE * STASH_BYTES / 4]: STASH bytes per segment */
+         uint32_t*                     seg_cont )  /* table index of byte STASH of a longer segment */
 {
     __shared__ uint32_t sBase, sNext, sK0;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
     uint32_t xcc;
     asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"( xcc ) );
     xcc &= WALK_QUEUES - 1;
@@ -215,11 +256,10 @@ k_walk( const BlockMeta* __restrict__ meta,
         const uint32_t total = plan->q_total[q];
         if ( total == 0 ) continue;
         for ( ;; ) {
-            __syncthreads();   /* everyone is done with sBase / sNext / sK0 of the previous chunk */
+            __syncthreads();   /* everyone is done with sBase / sK0 of the previous claim */
             if ( tid == 0 ) {
                 const uint32_t base = atomicAdd( &plan->ctr[q], chunk );
                 sBase = base;
-                sNext = WALK_THREADS;
                 /* last entry k in [qb, qe) with pre[k] <= base */
                 uint32_t lo = qb, hi = qe;
                 while ( hi - lo > 1 ) {
@@ -229,79 +269,89 @@ k_walk( const BlockMeta* __restrict__ meta,
                 sK0 = lo;
             }
             __syncthreads();
-            const uint32_t base = sBase;
+            uint32_t base = sBase;
             if ( base >= total ) break;   /* queue exhausted (the counter only grows) */
-            const uint32_t cnt = total - base < chunk ? total - base : chunk;
+            const uint32_t claimEnd = total - base < chunk ? total : base + chunk;
             uint32_t k = sK0;
-            uint32_t curBlock = 0xFFFFFFFFu, N = 0, stride = 1, origPtr = 0, k0 = 0;
-            const uint32_t* tab = nullptr;
-            uint32_t my = tid;
-            while ( my < cnt ) {
-                const uint32_t flat = base + my;
-                while ( k + 1 < qe && flat >= pre[k + 1] ) ++k;
+            /* the runs of the claim that belong to one block each */
+            while ( base < claimEnd ) {
+                while ( k + 1 < qe && base >= pre[k + 1] ) ++k;      /* (blocks without segments are skipped) */
+                const uint32_t runEnd = ( k + 1 < qe && pre[k + 1] < claimEnd ) ? pre[k + 1] : claimEnd;
+                const uint32_t cnt = runEnd - base;
                 const uint32_t b = blk[k];
-                const uint32_t j = flat - pre[k];
-                if ( b != curBlock ) {
-                    curBlock = b;
-                    N = meta[b].n;
-                    stride = meta[b].seg_stride;
-                    origPtr = meta[b].orig_ptr;
-                    k0 = ( N + stride - 1 ) / stride;
-                    tab = tab_buf + (size_t)b * TAB_STRIDE;
-                }
-                const size_t sidx = (size_t)b * SEG_STRIDE + j;
-                uint32_t p = j < k0 ? j * stride : origPtr;
-                uint32_t e = tab[p];
-                uint32_t len = 0;
-                {
-                    /* measure the segment and keep its first STASH_BYTES bytes (walk order) in the segment's own
-                     * 64-B line, 16 bytes per store: k_emit then needs no second gather pass for them */
-                    uint4* const line = reinterpret_cast<uint4*>( stash + sidx * ( STASH_BYTES / 4 ) );
-                    bool done = false;
+                const uint32_t j0 = base - pre[k];
+                const uint32_t N = meta[b].n, stride = meta[b].seg_stride, origPtr = meta[b].orig_ptr;
+                const uint32_t k0 = ( N + stride - 1 ) / stride;
+                const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+                const size_t segBase = (size_t)b * SEG_STRIDE;
+                uint32_t* const stashOfBlock = stash + segBase * ( STASH_BYTES / 4 );
+                __syncthreads();           /* the previous run's sNext has been read by everybody */
+                if ( tid == 0 ) sNext = WALK_THREADS;
+                __syncthreads();
+
+                uint32_t my = tid;         /* segment of the run this lane works on / asks for */
+                bool idle = true;          /* no segment under way */
+                uint32_t j = 0, p = 0, e = 0, len = 0, piece = 0;
+                for ( ;; ) {
+                    if ( idle && my < cnt ) {
+                        j = j0 + my;
+                        p = j < k0 ? j * stride : origPtr;
+                        e = tab[p];
+                        len = 0;
+                        piece = 0;
+                        idle = false;
+                    }
+                    if ( __ballot( !idle ) == 0 ) break;     /* this wave's lanes have found no more segments */
+                    if ( !idle ) {
+                        uint32_t w[4] = { 0, 0, 0, 0 };
+                        bool done = false;
+                        if ( piece == STASH / 16 ) __builtin_nontemporal_store( p, seg_cont + segBase + j );   /* table index of byte STASH */
+                        /* four steps per look at `done`: a lane whose segment ends inside the four goes on in place (it
+                         * re-reads its last entry, adds nothing) instead of costing every step a change of the execution mask */
 #pragma unroll
-                    for ( uint32_t quad = 0; quad < STASH_BYTES / 16; ++quad ) {
-                        if ( !done ) {
-                            uint32_t w[4] = { 0, 0, 0, 0 };
-                            /* four steps per look at `done`: a lane whose segment ends inside the four goes on in place
-                             * (it re-reads its last entry, adds nothing) instead of costing every step a change of the
-                             * execution mask */
+                        for ( uint32_t i = 0; i < 16; i += 4 ) {
+                            if ( !done ) {
 #pragma unroll
-                            for ( uint32_t i = 0; i < 16; i += 4 ) {
-                                if ( !done ) {
-#pragma unroll
-                                    for ( uint32_t k = i; k < i + 4; ++k ) {
-                                        const uint32_t live = done ? 0u : 1u;
-                                        w[k >> 2] |= done ? 0u : ( e & 0xFFu ) << ( 8 * ( k & 3u ) );
-                                        len += live;
-                                        p = done ? p : ( e >> 8 ) & LF_MASK;
-                                        e = tab[p];
-                                        done = ( e & MARK ) || len >= N;
-                                    }
+                                for ( uint32_t s4 = i; s4 < i + 4; ++s4 ) {
+                                    const uint32_t live = done ? 0u : 1u;
+                                    w[s4 >> 2] |= done ? 0u : ( e & 0xFFu ) << ( 8 * ( s4 & 3u ) );
+                                    len += live;
+                                    p = done ? p : ( e >> 8 ) & LF_MASK;
+                                    e = tab[p];
+                                    done = ( e & MARK ) || len >= N;
                                 }
                             }
-                            /* written once, read much later by k_emit: keep it out of the way of the table lines in L2 */
-                            {
-                                uint32_t* const q = reinterpret_cast<uint32_t*>( line + quad );
-                                __builtin_nontemporal_store( w[0], q );
-                                __builtin_nontemporal_store( w[1], q + 1 );
-                                __builtin_nontemporal_store( w[2], q + 2 );
-                                __builtin_nontemporal_store( w[3], q + 3 );
-                            }
+                        }
+                        if ( piece < STASH / 16 ) {
+                            /* the segment's first STASH bytes, walk order, 16 bytes per store: k_emit then needs no second
+                             * gather pass for them.  Written once, read much later: kept out of the way of the table lines */
+                            uint32_t* const out = stashOfBlock + (size_t)j * ( STASH / 4 ) + 4 * piece;
+                            __builtin_nontemporal_store( w[0], out );
+                            __builtin_nontemporal_store( w[1], out + 1 );
+                            __builtin_nontemporal_store( w[2], out + 2 );
+                            __builtin_nontemporal_store( w[3], out + 3 );
+                        }
+                        ++piece;
+                        if ( done ) {
+                            __builtin_nontemporal_store( len, seg_len + segBase + j );
+                            const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
+                            __builtin_nontemporal_store( ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu, seg_succ + segBase + j );
+                            idle = true;
                         }
                     }
-                    if ( !done ) {
-                        __builtin_nontemporal_store( p, seg_cont + sidx );   /* table index of byte STASH_BYTES */
-                        do {
-                            ++len;
-                            p = ( e >> 8 ) & LF_MASK;
-                            e = tab[p];
-                        } while ( !( e & MARK ) && len < N );
+                    /* the lanes that are through take the next segments of the run: one LDS atomic per wave */
+                    {
+                        const uint64_t asking = __ballot( idle );
+                        if ( asking != 0 ) {
+                            uint32_t first = 0;
+                            if ( lane == (uint32_t)__builtin_ctzll( asking ) ) first = atomicAdd( &sNext, (uint32_t)__popcll( asking ) );
+                            first = (uint32_t)__builtin_amdgcn_readlane( (int)first, __builtin_ctzll( asking ) );
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( asking >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)asking, 0 ) );
+                            if ( idle ) my = first < cnt ? first + rank : cnt;     /* (the counter is left alone once it has passed the end) */
+                        }
                     }
-                    __builtin_nontemporal_store( len, seg_len + sidx );
-                    const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
-                    __builtin_nontemporal_store( ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu, seg_succ + sidx );
                 }
-                my = atomicAdd( &sNext, 1u );
+                base = runEnd;
             }
         }
     }
@@ -314,6 +364,7 @@ k_walk( const BlockMeta* __restrict__ meta,
  * 16-byte units.  The second full gather pass and its partial-line writes (120 GB read + 25 GB written per 2 GiB, PMC)
  * are gone.  Output addresses run backwards: byte i of the segment at offset `off` is R[N - 1 - off - i].
  */
+template<uint32_t STASH = STASH_BYTES, uint32_t STAGE = ( STASH <= 128 ? EMIT_STAGE : 3 * EMIT_STAGE )>
 __global__ __launch_bounds__( EMIT_THREADS ) void
 k_emit( const BlockMeta* __restrict__ meta,
         const uint32_t* __restrict__  tab_buf,
@@ -321,7 +372,7 @@ k_emit( const BlockMeta* __restrict__ meta,
         const uint32_t* __restrict__  stash,
         uint8_t* __restrict__         r_buf )
 {
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t image[EMIT_STAGE + 16];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t image[STAGE + 16];
     __shared__ uint32_t sLow;    /* lowest output address of the piece */
     const uint32_t b = blockIdx.y;
     const BlockMeta mt = meta[b];
@@ -347,15 +398,14 @@ k_emit( const BlockMeta* __restrict__ meta,
     const uint32_t imageBase = low & ~15u;                /* the image mirrors memory from a 16-byte boundary */
 
     if ( t < count ) {
-        const uint32_t kept = len < STASH_BYTES ? len : STASH_BYTES;
-        const uint4* const line = reinterpret_cast<const uint4*>( stash + ( base + seg ) * ( STASH_BYTES / 4 ) );
+        const uint32_t kept = len < STASH ? len : STASH;
+        const uint4* const line = reinterpret_cast<const uint4*>( stash + base * ( STASH_BYTES / 4 ) + (size_t)seg * ( STASH / 4 ) );
         uint32_t a = N - 1 - off;                         /* address of byte 0 */
         const auto put = [&] ( uint32_t addr, uint32_t byte ) {
             const uint32_t pos = addr - imageBase;
-            if ( pos < EMIT_STAGE ) image[pos] = (uint8_t)byte; else R[addr] = (uint8_t)byte;   /* oversized piece */
+            if ( pos < STAGE ) image[pos] = (uint8_t)byte; else R[addr] = (uint8_t)byte;   /* oversized piece */
         };
-#pragma unroll
-        for ( uint32_t quad = 0; quad < STASH_BYTES / 16; ++quad ) {
+        const auto sixteen = [&] ( uint32_t quad ) {
             if ( quad * 16 < kept ) {
                 const uint4 v = line[quad];
                 const uint32_t w[4] = { v.x, v.y, v.z, v.w };
@@ -364,11 +414,17 @@ k_emit( const BlockMeta* __restrict__ meta,
                     if ( quad * 16 + i < kept ) put( a - ( quad * 16 + i ), ( w[i >> 2] >> ( 8 * ( i & 3 ) ) ) & 0xFFu );
                 }
             }
+        };
+        if constexpr ( STASH <= 128 ) {
+#pragma unroll
+            for ( uint32_t quad = 0; quad < STASH / 16; ++quad ) sixteen( quad );
+        } else {
+            for ( uint32_t quad = 0; quad * 16 < kept; ++quad ) sixteen( quad );
         }
-        if ( len > STASH_BYTES ) {
+        if ( len > STASH ) {
             uint32_t p = rec.w;
-            a -= STASH_BYTES;
-            for ( uint32_t i = STASH_BYTES; i < len; ++i ) {
+            a -= STASH;
+            for ( uint32_t i = STASH; i < len; ++i ) {
                 const uint32_t e = tab[p];
                 put( a, e & 0xFFu );
                 --a;
@@ -380,7 +436,7 @@ k_emit( const BlockMeta* __restrict__ meta,
 
     /* image -> memory: whole aligned 16-byte units where the piece covers them, bytes at its two ends (the units there
      * are shared with the neighbouring pieces) */
-    const uint32_t endPos = ( top - imageBase + 1 ) < EMIT_STAGE ? ( top - imageBase + 1 ) : EMIT_STAGE;   /* exclusive */
+    const uint32_t endPos = ( top - imageBase + 1 ) < STAGE ? ( top - imageBase + 1 ) : STAGE;   /* exclusive */
     const uint32_t beginPos = low - imageBase;
     for ( uint32_t unit = t * 16; unit < endPos; unit += EMIT_THREADS * 16 ) {
         if ( unit >= beginPos && unit + 16 <= endPos ) {
