@@ -414,7 +414,7 @@ ensureOutput( mi355x_bz2_ctx* c, uint64_t size )
 namespace
 {
 const char* const KERNEL_NAMES[] = {
-    "k_huff", "k_mtf<272>", "k_bwt_build", "k_walk", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
+    "(k_huff: gone)", "k_mtf<272>", "k_bwt_build", "k_walk", "k_link2", "k_emit", "k_replicate", "k_rle<false>",
     "k_rle<true>", "k_crc", "k_walk_plan", "k_mtf<144>", "k_hscan", "k_hsym"
 };
 constexpr uint32_t N_KERNELS = sizeof( KERNEL_NAMES ) / sizeof( KERNEL_NAMES[0] );
@@ -578,7 +578,7 @@ mi355x_bz2_create( const mi355x_bz2_config* config, mi355x_bz2_ctx** out )
         int leastPriority = 0, greatestPriority = 0;   /* numerically lower = higher priority */
         (void)hipDeviceGetStreamPriorityRange( &leastPriority, &greatestPriority );
         for ( int g = 1; g < MAX_GROUPS; ++g ) {
-            /* gstream[MAX_GROUPS - 1] serves the expensive group: its k_huff is the longest chain of a batch */
+            /* gstream[MAX_GROUPS - 1] serves the expensive group: its scan is the longest chain of a batch */
             const int priority = g == MAX_GROUPS - 1 ? greatestPriority : ( leastPriority + greatestPriority ) / 2;
             if ( hipStreamCreateWithPriority( &c->gstream[g], hipStreamNonBlocking, priority ) != hipSuccess ) {
                 mi355x_bz2_destroy( c );
@@ -980,16 +980,14 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
 
     /* ---- plan: cost estimate, groups, slots, work order --------------------------------------------------------
      * cost = estimated compressed size (distance to the next requested offset, or to the end of the input).
-     * k_huff is one serial chain per block: a launch lasts as long as its LARGEST block, and its waves are bound by
-     * the scalar unit (one per CU), so they slow each other down beyond a few waves per CU.  Everything behind it
-     * (MTF, BWT, walk, RLE, CRC) is throughput work of about the same size for every block.  The batch is therefore
-     * cut into groups, each with its own HIP stream, such that the throughput work starts early and never runs dry:
+     * The group-start scan (k_hscan<1>) is one serial chain per block: a launch lasts as long as its LARGEST block.
+     * Everything behind it (symbols, MTF, BWT, walk, RLE, CRC) is throughput work of about the same size for every block.
+     * The batch is therefore cut into groups, each with its own HIP stream, such that the throughput work starts early and
+     * never runs dry:
      *   - the "expensive" group: blocks above 45 % of the largest cost, if they are a minority (incompressible blocks
-     *     among text).  Its k_huff starts at once and runs beside everything else on a high-priority stream.
-     *   - the other blocks, sorted by cost, in up to MAX_CHUNKS chunks of growing size.  All k_huff launches start
-     *     together; a chunk of cheap blocks is through k_huff early, and its MTF .. RLE kernels run while the later
-     *     chunks are still in k_huff.  (Chaining the k_huff launches instead was measured to be slower: a k_huff wave
-     *     is latency bound, co-resident waves barely slow it down.)
+     *     among text).  Its scan starts at once and runs beside everything else on a high-priority stream.
+     *   - the other blocks, sorted by cost, in up to MAX_CHUNKS chunks of growing size.  All scans start together; a chunk
+     *     of cheap blocks is through early, and its MTF .. RLE kernels run while the later chunks are still being scanned.
      * Inside a group the stage-1 kernels start their largest blocks first (LPT).
      * Slots: group g occupies slots [groupFirst[g], +groupCount[g]) of every per-block buffer; results are mapped
      * back to input order. */
@@ -1021,8 +1019,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     const uint32_t nCheap = n - nExpensive;
     uint32_t nChunks = 1;
     if ( split ) {
-        /* measured on MI355X: a lone k_huff wave takes about 5.5 ns per compressed bit; the kernels behind k_huff
-         * together about 0.04 ms per block when the GPU is full */
+        /* measured on MI355X (round 1, and still the right proportion): a lone stage-1 wave takes about 5.5 ns per
+         * compressed bit; the kernels behind it together about 0.04 ms per block when the GPU is full */
         const double huffMs = (double)cost[ascending[nCheap - 1]] * 5.5e-6;
         const double restMs = (double)nCheap * 0.04;
         const double ratio = restMs / std::max( huffMs, 1e-3 );
@@ -1085,22 +1083,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
     const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
 
-    /* tuning knobs: most k_huff workgroups of a cheap group / of the expensive group (0 = one per block) */
-    const char* hc = std::getenv( "MI355X_BZ2_HUFF_GRID" );
-    const uint32_t huffCap = hc != nullptr && std::atoi( hc ) > 0 ? (uint32_t)std::atoi( hc ) : 0xFFFFFFFFu;
-    /* Huffman stage: "scan" = k_hscan + k_hsym (group starts by pointer doubling, then one lane per group),
-     * "window" = k_huff (one serial chain per block) */
-    const char* hm = std::getenv( "MI355X_BZ2_HUFF" );
-    const bool useScan = !( hm != nullptr && std::strcmp( hm, "window" ) == 0 );
-    const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: wavefronts per block in k_hscan (1, 2, 4, 8) */
+    const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: 1 = k_hscan<1>, 4 / 8 = k_hscan_spec<4 / 8>, whatever the batch size */
     const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;
-    /* 1: k_hscan_pc (producer + consumer wave) where one wave per block is chosen.  Measured slower than k_hscan<1>
-     * (DESIGN.md section 4): both are bound by instruction issue, and the pair does ~25 % more of it */
-    const char* spc = std::getenv( "MI355X_BZ2_SCAN_PC" );
-    const bool scanPc = spc != nullptr && spc[0] == '1';
-    /* 0: the waves of a block share the rows of one build (k_hscan<4 / 8>) instead of taking one group each (k_hscan_spec) */
-    const char* ssp = std::getenv( "MI355X_BZ2_SCAN_SPEC" );
-    const bool scanSpec = !( ssp != nullptr && ssp[0] == '0' );
     /* most workgroups of a k_hscan<1> launch (0: one per block).  Ten of them fill the LDS of a CU for as long as
      * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
     const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
@@ -1134,8 +1118,6 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     const bool mtfNarrow = mn != nullptr && mn[0] == '1';
     const char* st = std::getenv( "MI355X_BZ2_SCAN_TUNE" );
     const uint32_t scanTune = st != nullptr ? (uint32_t)std::atoi( st ) : 0u;
-    const char* hce = std::getenv( "MI355X_BZ2_HUFF_GRID_EXPENSIVE" );
-    const uint32_t huffCapExpensive = hce != nullptr && std::atoi( hce ) > 0 ? (uint32_t)std::atoi( hce ) : 0xFFFFFFFFu;
     for ( int launch = 0; launch < nGroups; ++launch ) {
         /* the expensive group is queued first, then the chunks from cheap to less cheap */
         const int g = expensiveGroup >= 0 ? ( launch == 0 ? expensiveGroup : launch - 1 ) : launch;
@@ -1161,7 +1143,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         uint32_t* const walkPre = c->dWalkPre + (size_t)g * ( c->capacity + 16 );
         const dim3 walkGrid( WALK_QUEUES * wgsPerXcd );
 
-        if ( useScan ) {
+        {
             ScanMeta* const smeta = c->dSmeta + first;
             HuffTables* const htab = c->dHtab + first;
             uint32_t* const gpos = c->dGpos + (size_t)first * GPOS_STRIDE;
@@ -1180,25 +1162,12 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                 scanWaves = scanMixed >= 4 ? scanMixed : ( m <= 128 ? 8u : 4u );
             }
             const auto* const inWords = reinterpret_cast<const uint32_t*>( inBase );
-            if ( scanWaves >= 8 && scanSpec ) {
+            if ( scanWaves >= 8 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<8>, dim3( m ), dim3( 512 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
-            } else if ( scanWaves >= 4 && scanSpec ) {
+            } else if ( scanWaves >= 4 ) {
                 TIMED_LAUNCH( c, g, q, 12, k_hscan_spec<4>, dim3( m ), dim3( 256 ), 0, q, inWords, inSize, c->dOffsets + first,
                               meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune );
-            } else if ( scanWaves >= 8 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<8>, dim3( m ), dim3( 512 ), sizeof( ScanShared<8> ), q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
-            } else if ( scanWaves >= 4 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<4>, dim3( m ), dim3( 256 ), sizeof( ScanShared<4> ), q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
-            } else if ( scanWaves >= 2 ) {
-                TIMED_LAUNCH( c, g, q, 12, k_hscan<2>, dim3( m ), dim3( 128 ), sizeof( ScanShared<2> ), q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, static_cast<uint32_t*>( nullptr ) );
-            } else if ( scanPc ) {
-                /* one block per workgroup, producer + consumer wave (k_hscan_pc) */
-                TIMED_LAUNCH( c, g, q, 12, k_hscan_pc, dim3( m ), dim3( 128 ), 0, q, inWords, inSize, c->dOffsets + first,
-                              meta, hmeta, smeta, sel, stb, htab, gpos, m, order );
             } else {
                 uint32_t* scanQueue = nullptr;
                 uint32_t grid = m;
@@ -1216,11 +1185,6 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                                 sizeof( SymShared<T> ), q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym )
             if ( regs.sym >= 512 ) { HSYM( 512 ); } else if ( regs.sym >= 256 ) { HSYM( 256 ); } else { HSYM( 128 ); }
 #undef HSYM
-        } else {
-            const uint32_t huffGrid = std::min( ( m + HUFF_WAVES - 1 ) / HUFF_WAVES, g == expensiveGroup ? huffCapExpensive : huffCap );
-            TIMED_LAUNCH( c, g, q, 0, k_huff, dim3( huffGrid ), dim3( 64 * HUFF_WAVES ), 0, q,
-                          reinterpret_cast<const uint32_t*>( inBase ), inSize, c->dOffsets + first, meta, hmeta, sel, sym, stb,
-                          m, order );
         }
 #define MTF256( STRIDE, STREAM, INDEX ) \
         do { \

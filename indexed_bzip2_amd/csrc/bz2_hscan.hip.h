@@ -1,13 +1,13 @@
 /**
- * bz2_hscan.hip.h -- Huffman stage in two kernels that break the one-serial-chain-per-block form of k_huff.
+ * bz2_hscan.hip.h -- Huffman stage in two kernels that break the one-serial-chain-of-codes-per-block form of a bzip2 decoder.
  *
  * The Huffman stream of a bzip2 block switches its code table every 50 symbols (Block::readBlockData,
  * src/indexed_bzip2/bzip2.hpp:709-723), so a decoder that starts in the middle of a block knows neither the code
  * alignment nor the table.  But the ONLY thing that is serial is the bit position at which every 50-symbol group starts:
  * once those positions are known, all groups (18 000 per level-9 block) decode independently.
  *
- *   k_hscan  K wavefronts per block (K = 1 for large batches, 4 or 8 when few blocks have to be through quickly).  Wave 0
- *            parses header, selectors, code lengths and builds the canonical tables as in k_huff.  Then, group by
+ *   k_hscan  one wavefront per block (large batches; k_hscan_spec below when few blocks have to be through quickly).  It
+ *            parses header, selectors, code lengths and builds the canonical tables.  Then, group by
  *            group: all 64 lanes look up the length of the code that WOULD start at each of S consecutive bit
  *            positions (S = 64..1024, adapted to the table), which gives the successor array J1[i] = i + len(i); five
  *            rounds of pointer doubling in LDS, J2k[i] = Jk[Jk[i]], give J2, J4, J8, J16, J32, and the group that starts
@@ -15,16 +15,17 @@
  *            round trips instead of ~50 chain steps on the scalar unit, no symbol is produced, nothing is written but
  *            one u32 per group.  End-of-block, "no code matches" and end-of-input positions are absorbing entries
  *            (they point to themselves), so the first group that runs into one of them is found exactly; consecutive
- *            groups with the same table share one set of arrays.  With K > 1 the K waves share the rows of every build
- *            (one barrier per round of doubling, two sets of arrays in turn): a lone wave is bound by its instruction
- *            issue rate, which the wide spans of incompressible blocks (512 positions per group) feel most.
+ *            groups with the same table share one set of arrays.  (The helpers keep their parameter K = wavefronts that
+ *            share the rows of a build: round 2 measured K = 2, 4, 8 -- one barrier per round of doubling, 31 -> 24 ms
+ *            for an incompressible block with eight waves, no more -- and a producer / consumer pair of waves, 10 to 20 %
+ *            slower than one wave; both are gone, k_hscan_spec took their place.  Only K = 1 is instantiated.)
  *   k_hsym   one LANE per group: decodes its 50 symbols from the known start with the known table (per-lane bit reader,
  *            {length, symbol} look-up table in LDS, canonical range search for long codes =
  *            HuffmanCodingShortBitsCached::decode / decodeLong, src/huffman/HuffmanCodingShortBitsCached.hpp:98-150).
  *            The lane of the block's last group applies the reference's end-of-input / invalid-code rules symbol by
  *            symbol and writes the block's final record.
  *
- * k_mtf (bz2_stage1.hip.h) consumes the symbols exactly as it did from k_huff.
+ * k_mtf (bz2_stage1.hip.h) consumes the symbols.
  */
 #pragma once
 
@@ -149,9 +150,9 @@ scan_sync()
  * Codes longer than the index bits of the length table are rare per position but present in most rows: their positions
  * are collected (arrays b and c are free until the first doubling) and resolved in ONE pass of range comparisons
  * instead of one per row. */
-/* parts of scan_build: J1 / rounds only (k_hscan_pc); SCAN_ENDS: J1, the rounds up to J16 and then, for the first 64 x
- * endRows positions, where the 50-symbol group that starts there ends (k_hscan_spec) */
-constexpr int SCAN_ALL = 0, SCAN_J1_ONLY = 1, SCAN_LEVELS_ONLY = 2, SCAN_ENDS = 3;
+/* parts of scan_build: all of it (k_hscan); SCAN_ENDS: J1, the rounds up to J16 and then, for the first 64 x endRows
+ * positions, where the 50-symbol group that starts there ends (k_hscan_spec) */
+constexpr int SCAN_ALL = 0, SCAN_ENDS = 3;
 
 template<uint32_t K, uint32_t RW, bool NEAR_END, int PART = SCAN_ALL, uint32_t RING = SCAN_RING_ENTRIES>
 __device__ __forceinline__ void
@@ -172,11 +173,6 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
     uint32_t* const pending = reinterpret_cast<uint32_t*>( base + LEV_BYTES ) + wave * ( LEV_ENTRIES / K );
     const uint32_t first = 64 * wave + lane;     /* my position in row 0 */
     uint32_t own[RW], v20s[RW];
-    if constexpr ( PART == SCAN_LEVELS_ONLY ) {
-        /* J1 is in array a already (another wave produced it) */
-#pragma unroll
-        for ( uint32_t j = 0; j < RW; ++j ) own[j] = *reinterpret_cast<const uint16_t*>( mine + STEP * j );
-    } else {
     {
         /* 64 stream bits from the lane's word on: one 8-byte read per row at a fixed distance from the first row's */
         const uint32_t a0 = p + first;
@@ -238,9 +234,7 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
 #pragma unroll
         for ( uint32_t j = 0; j < RW; ++j ) own[j] = *reinterpret_cast<const uint16_t*>( mine + STEP * j );
     }
-    }
-    if constexpr ( PART == SCAN_J1_ONLY ) return;
-    if constexpr ( PART == SCAN_ALL || PART == SCAN_ENDS ) scan_sync<K>();
+    scan_sync<K>();
     /* one round of doubling: own[j] = src[own[j]], the same into dst */
 #define SCAN_LEVEL( src, toDst ) \
     _Pragma( "unroll" ) for ( uint32_t j = 0; j < RW; ++j ) own[j] = *reinterpret_cast<const uint16_t*>( src + own[j] ); \
@@ -267,13 +261,11 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
         return;
     }
     if ( firstOnly ) {
-        if constexpr ( PART != SCAN_LEVELS_ONLY ) {   /* (the consumer of k_hscan_pc reads J16 twice instead) */
-            if ( wave == 0 ) {
-                const uint32_t j32 = *reinterpret_cast<const uint16_t*>( C + own[0] );
-                if ( lane == 0 ) *reinterpret_cast<uint16_t*>( base ) = (uint16_t)j32;
-            }
-            scan_sync<K>();
+        if ( wave == 0 ) {
+            const uint32_t j32 = *reinterpret_cast<const uint16_t*>( C + own[0] );
+            if ( lane == 0 ) *reinterpret_cast<uint16_t*>( base ) = (uint16_t)j32;
         }
+        scan_sync<K>();
     } else {
         SCAN_LEVEL( C, 0 )   /* J32 -> a (kept) */
     }
@@ -635,7 +627,7 @@ done:
 #undef FAIL
     if ( lane == 0 ) {
         ScanHeader h;
-        const uint64_t posBase = br.pos & ~31ull;   /* bit positions of the scan are 32-bit, relative to this word, as in k_huff */
+        const uint64_t posBase = br.pos & ~31ull;   /* bit positions of the scan are 32-bit, relative to this word */
         const uint64_t wordsLeft = ( ( in_size_bytes + 3 ) >> 2 ) - ( posBase >> 5 );
         h.enc_size = encSize;
         h.pos_base = posBase;
@@ -711,6 +703,7 @@ k_hscan( const uint32_t* __restrict__ in_words,
                                                   the host) until none is left, so that a grid smaller than the batch -- one
                                                   that leaves LDS to the kernels of other streams -- still decodes all of it */
 {
+    static_assert( K == 1, "one wavefront per block: the forms with shared rows were measured and dropped (DESIGN.md)" );
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( ScanShared<K> ) */
     ScanShared<K>& sh = *reinterpret_cast<ScanShared<K>*>( ldsAtLaunch );
     for ( uint32_t slotIndex = blockIdx.x;; slotIndex += gridDim.x ) {
@@ -1210,326 +1203,6 @@ k_hscan_spec( const uint32_t* __restrict__ in_words,
         sm.n_groups = nGroups;
         sm.terminal = terminal;
         sm.symbol_count = sh.hdr.symbol_count;
-        smeta[b] = sm;
-    }
-}
-
-/* =============================================================================================================
- * k_hscan_pc: the scan with TWO waves per block, a producer and a consumer.
- *
- * With one wave per block a group costs the sum of two dependent chains: J1 (stream read, length look-up, long-code pass)
- * and the doubling rounds + chase.  Here wave 1 produces J1 of the NEXT unit (a unit = the groups of one build) into the
- * other slot while wave 0 runs the rounds and the chase of the current one; one barrier per unit.  The producer has to
- * guess where the next unit starts -- the current start plus the lengths of the table's last groups, +- 12 % -- and
- * lays its window so that every start in that range has its groups inside.  A start outside the window ("miss": the
- * first groups of a table, a stray long group) makes the producer build again from the true start while the consumer
- * waits: correctness never depends on the guess.
- *
- * All decisions that both waves take (table, groups per build, rows, hit or miss) are functions of the shared state of
- * the unit, which the consumer writes for the NEXT unit into the other of two state buffers: nothing is read and written
- * in the same unit.
- * ============================================================================================================= */
-struct PcSlotInfo
-{
-    uint32_t table, base, rows, valid;   /* array a of the slot = J1 under `table` for bit positions base .. base + 64 rows */
-};
-
-struct PcState
-{
-    uint32_t g, p, stop, forceFull;
-    uint32_t est[8];                     /* per table: upper estimate of a group's length in bits (sizes the spans), 0 = not seen yet */
-    uint32_t mid[8];                     /* per table: running mean of the group lengths (says where the next unit starts) */
-    PcSlotInfo info;                     /* of the slot this unit uses (written by the producer during the previous unit) */
-};
-
-struct PcShared
-{
-    ScanShared<2> scan;                  /* tables, ring, header, two slots */
-    PcState st[2];
-};
-
-/** Rows for a producer's window, rounded up to the next instance. */
-__device__ __forceinline__ uint32_t
-pc_round_rows( uint32_t rows )
-{
-    return rows <= 6 ? rows : ( rows <= 8 ? 8u : ( rows <= 10 ? 10u : ( rows <= 12 ? 12u : 16u ) ) );
-}
-
-template<int PART>
-__device__ __forceinline__ void
-pc_build_rows( uint32_t rows, bool nearEnd, ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p,
-               uint32_t sizeBits, const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool one, uint32_t lane )
-{
-#define PC_CASE( n ) case n: scan_build<1, n, false, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, 0 ); break;
-    if ( nearEnd ) {
-        scan_build<1, 16, true, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, 0 );
-        return;
-    }
-    switch ( rows ) {
-    PC_CASE( 1 ) PC_CASE( 2 ) PC_CASE( 3 ) PC_CASE( 4 ) PC_CASE( 5 ) PC_CASE( 6 ) PC_CASE( 8 ) PC_CASE( 10 ) PC_CASE( 12 )
-    default: scan_build<1, 16, false, PART>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, 0 ); break;
-    }
-#undef PC_CASE
-}
-
-__global__ __launch_bounds__( 128 ) void
-k_hscan_pc( const uint32_t* __restrict__ in_words,
-            uint64_t                     in_size_bytes,
-            const uint64_t* __restrict__ offsets,
-            BlockMeta* __restrict__      meta,
-            HuffMeta* __restrict__       hmeta,
-            ScanMeta* __restrict__       smeta,
-            uint8_t*                     sel_buf,
-            uint8_t* __restrict__        stb_buf,
-            HuffTables* __restrict__     tab_buf,
-            uint32_t* __restrict__       gpos_buf,
-            uint32_t                     n_blocks,
-            const uint32_t* __restrict__ order )
-{
-    __shared__ PcShared shared;
-    ScanShared<2>& sh = shared.scan;
-    const uint32_t slotIndex = blockIdx.x;
-    if ( slotIndex >= n_blocks ) return;
-    const uint32_t b = sfl( order[slotIndex] );
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = sfl( threadIdx.x >> 6 );      /* 0: consumer (and parser), 1: producer */
-    uint8_t* const sel = sel_buf + (size_t)b * SEL_STRIDE;
-    uint32_t* const gpos = gpos_buf + (size_t)b * GPOS_STRIDE;
-    const uint64_t start = offsets[b];
-
-    if ( wave == 0 ) {
-        scan_parse<2>( sh, in_words, in_size_bytes, start, sel, stb_buf, tab_buf + b, b, lane );
-        __threadfence_block();   /* the selectors are read back below */
-        if ( lane < sizeof( PcState ) / 4 ) reinterpret_cast<uint32_t*>( &shared.st[0] )[lane] = 0;
-    }
-    __syncthreads();
-    if ( wave == 0 && lane == 0 ) shared.st[0].p = sh.hdr.p0;
-    __syncthreads();
-
-    const uint32_t active = sfl( sh.hdr.active );
-    int32_t status = (int32_t)sfl( (uint32_t)sh.hdr.status );
-    const uint32_t nSel = sfl( sh.hdr.n_sel );
-    const uint32_t sizeBits = sfl( sh.hdr.size_bits );
-    const uint32_t nWords = sfl( sh.hdr.n_words );
-    const uint64_t posBase = ( (uint64_t)sfl( (uint32_t)( sh.hdr.pos_base >> 32 ) ) << 32 ) | sfl( (uint32_t)sh.hdr.pos_base );
-    uint32_t nGroups = 0, terminal = 0;
-
-    if ( active ) {
-        const uint32_t* const words = in_words + ( posBase >> 5 );
-        /* producer: the stream ring (words [wHi - 256, wHi) present, the next 64 on their way) and the code ranges of the
-         * table it last produced for */
-        uint32_t wHi = 0, pend = 0;
-        if ( wave == 1 && lane < nWords ) pend = words[lane];
-        uint32_t lim[10] = {};
-        uint32_t eobLo = 0, eobHi = 0, limT = 0xFFFFFFFFu;
-        uint32_t lastS[2] = { 0, 0 };
-        /* both: selectors of groups [64 k, 64 k + 64), one per lane, and of the next 64 */
-        uint32_t selWindow = 0;
-        uint32_t selV = sel[lane];
-        uint32_t selNext = sel[64 + lane];
-        uint32_t gposV = 0;     /* consumer */
-
-        const auto tableOf = [&] ( uint32_t group ) {      /* group in this window of 64 or in the next */
-            return (uint32_t)__builtin_amdgcn_readlane( (int)( ( group >> 6 ) == selWindow ? selV : selNext ), group & 63u );
-        };
-        const auto runFrom = [&] ( uint32_t group, uint32_t t ) {   /* groups from `group` on with table t, inside its window */
-            const uint64_t same = __ballot( ( ( group >> 6 ) == selWindow ? selV : selNext ) == t ) >> ( group & 63u );
-            uint32_t run = (uint32_t)__builtin_ctzll( ~same );
-            if ( run > 64u - ( group & 63u ) ) run = 64u - ( group & 63u );
-            if ( run > nSel - group ) run = nSel - group;
-            if ( run > MAX_SCAN_GROUPS - group ) run = MAX_SCAN_GROUPS - group;
-            return run;
-        };
-        /* J1 of table t for rows x 64 positions from bit position base into slot s (producer) */
-        const auto produce = [&] ( uint32_t s, uint32_t t, uint32_t base, uint32_t rows, bool nearEnd ) {
-            while ( ( base >> 5 ) + ( SCAN_MAX_SPAN + 96 ) / 32 > wHi ) {
-                ring_put( sh.ring, wHi + lane, pend );
-                pend = 0;
-                        if ( wHi + 64 + lane < nWords ) pend = words[wHi + 64 + lane];
-                wHi += 64;
-            }
-            if ( t != limT ) {
-                const uint32_t mx = sfl( sh.minmax[t] ) >> 8;
-                const uint32_t limV = sh.limit[t][lane < mx ? lane : mx];
-#pragma unroll
-                for ( uint32_t l = 0; l < 10; ++l ) lim[l] = (uint32_t)__builtin_amdgcn_readlane( (int)limV, 11 + l );
-                eobLo = sfl( sh.eob_lo[t] );
-                eobHi = sfl( sh.eob_hi[t] );
-                limT = t;
-            }
-            const uint32_t S = 64 * rows;
-            ScanSlot& slot = sh.slot[s];
-            if ( S != lastS[s] ) {
-                if ( lane < 2 ) {
-                    const uint16_t v = (uint16_t)( 2 * ( S + lane ) );
-                    slot.at( 0, S + lane ) = v; slot.at( 1, S + lane ) = v; slot.at( 2, S + lane ) = v;
-                }
-                lastS[s] = S;
-            }
-            pc_build_rows<SCAN_J1_ONLY>( rows, nearEnd, slot, sh.lenlut[t], sh.ring, base, sizeBits, lim, eobLo, eobHi, false, lane );
-        };
-
-        for ( uint32_t unit = 0;; ++unit ) {
-            const PcState& now = shared.st[unit & 1u];
-            PcState& next = shared.st[( unit + 1 ) & 1u];
-            const uint32_t s = unit & 1u;
-            const uint32_t g = sfl( now.g ), p = sfl( now.p );
-            if ( sfl( now.stop ) ) {
-                terminal = 1;
-                nGroups = g;
-                break;
-            }
-            nGroups = g;
-            if ( g >= nSel ) { status = ST_SELECTOR_OVERRUN; break; }
-            if ( g >= MAX_SCAN_GROUPS ) { status = ST_DATA_OVERFLOW; break; }
-            if ( ( g >> 6 ) != selWindow ) {          /* the groups move on by less than a window per unit */
-                selWindow = g >> 6;
-                selV = selNext;
-                selNext = sel[64 * ( selWindow + 1 ) + lane];   /* may read past the block's selectors: never used */
-            }
-            /* the plan of this unit: table, groups that share the build, rows -- the same in both waves */
-            const uint32_t t = tableOf( g );
-            const uint32_t est = sfl( now.est[t] );
-            const bool nearEnd = p + SCAN_MAX_SPAN + 32 > sizeBits;
-            const bool full = est == 0 || sfl( now.forceFull ) != 0 || nearEnd;
-            const uint32_t need = est + ( est >> 3 ) + 16;       /* a group of this table: last one + 12 % + 16 bits */
-            uint32_t m = 1, rows = SCAN_ROWS;
-            if ( !full ) {
-                m = ( SCAN_MAX_SPAN - 24 ) / need;
-                const uint32_t run = runFrom( g, t );
-                if ( m > run ) m = run;
-                if ( m < 1 ) m = 1;
-                rows = pc_round_rows( ( m * need + 24 + 63 ) >> 6 );
-                if ( rows > SCAN_ROWS ) rows = SCAN_ROWS;
-            }
-            /* does the slot hold this table's J1 around p?  Then as many groups as fit behind p */
-            PcSlotInfo info = now.info;
-            info.table = sfl( info.table ); info.base = sfl( info.base ); info.rows = sfl( info.rows ); info.valid = sfl( info.valid );
-            bool hit = false;
-            if ( !full && info.valid && info.table == t && p >= info.base && p - info.base + need + 24 <= 64 * info.rows ) {
-                const uint32_t fit = ( 64 * info.rows - ( p - info.base ) - 24 ) / need;
-                m = m < fit ? m : fit;
-                hit = true;
-            }
-            if ( !hit ) {
-                if ( wave == 1 ) produce( s, t, p, rows, nearEnd );
-                info.table = t; info.base = p; info.rows = nearEnd ? SCAN_ROWS : rows; info.valid = 1;
-                __syncthreads();
-            }
-            const uint32_t S = 64 * info.rows;
-
-            if ( wave == 0 ) {
-                /* ---- consumer: doubling rounds on the slot, chase of up to m groups from p ---- */
-                ScanSlot& slot = sh.slot[s];
-                pc_build_rows<SCAN_LEVELS_ONLY>( info.rows, false, slot, nullptr, nullptr, 0, 0, lim, 0, 0, m == 1, lane );
-                const uint8_t* const J32 = slot.bytes();
-                const uint8_t* const J16 = slot.bytes() + 2 * LEV_BYTES;
-                const uint8_t* const J2 = slot.bytes() + LEV_BYTES;
-                uint32_t y = 2 * ( p - info.base ), done = 0, stop = 0, again = 0;
-                uint32_t estT = est, midT = sfl( now.mid[t] );
-                for ( uint32_t j = 0; j < m; ++j ) {
-                    /* 32 + 16 + 2 symbols; with a single group J32 was not built: J16 twice */
-                    const uint32_t q = m == 1 ? *reinterpret_cast<const uint16_t*>( J16 + *reinterpret_cast<const uint16_t*>( J16 + y ) )
-                                              : *reinterpret_cast<const uint16_t*>( J32 + y );
-                    const uint32_t r16 = *reinterpret_cast<const uint16_t*>( J16 + q );
-                    const uint32_t u = sfl( *reinterpret_cast<const uint16_t*>( J2 + r16 ) );
-                    if ( u == 2 * S ) {                   /* left the span: again from here, the first group with the full span */
-                        again = j == 0;
-                        break;
-                    }
-                    const uint32_t gg = g + j;
-                    gposV = lane == ( gg & 63u ) ? info.base + ( y >> 1 ) : gposV;
-                    if ( ( gg & 63u ) == 63u ) gpos[( gg & ~63u ) + lane] = gposV;
-                    ++done;
-                    if ( u == 2 * S + 2 ) {               /* end-of-block, no code or end of input inside this group */
-                        stop = 1;
-                        break;
-                    }
-                    const uint32_t d = ( u - y ) >> 1;
-                    estT = ( estT == 0 || d > estT ) ? d : estT - ( ( estT - d ) >> 2 );
-                    midT = midT == 0 ? d : (uint32_t)( (int32_t)midT + ( (int32_t)d - (int32_t)midT ) / 4 );
-                    y = u;
-                }
-                /* the state of the next unit (its slot info comes from the producer) */
-                if ( lane < 8 ) {
-                    next.est[lane] = lane == t ? estT : now.est[lane];
-                    next.mid[lane] = lane == t ? midT : now.mid[lane];
-                }
-                if ( lane == 0 ) {
-                    next.g = g + done;
-                    next.p = info.base + ( y >> 1 );
-                    next.stop = stop;
-                    next.forceFull = again;
-                }
-            } else {
-                /* ---- producer: J1 for the unit that follows, where it will probably start ---- */
-                PcSlotInfo ahead{ 0, 0, 0, 0 };
-                const uint32_t g2 = g + m;
-                if ( !full && g2 < nSel && g2 < MAX_SCAN_GROUPS && ( g2 >> 6 ) <= selWindow + 1 ) {
-                    const uint32_t t2 = tableOf( g2 );
-                    const uint32_t est2 = sfl( now.est[t2] );
-                    const uint32_t mid = sfl( now.mid[t] );
-                    if ( est2 != 0 && mid != 0 ) {
-                        /* the groups of this unit: around the table's running mean, +- 12 % (and 8 bits) each */
-                        const uint32_t slack = ( mid >> 3 ) + 8;
-                        const uint32_t lo = m * ( mid > slack + 50 ? mid - slack : 50u );      /* 50 symbols are at least 50 bits */
-                        const uint32_t hi = m * ( mid + slack );
-                        const uint32_t need2 = est2 + ( est2 >> 3 ) + 16;
-                        if ( hi - lo + need2 + 24 <= SCAN_MAX_SPAN ) {
-                            uint32_t m2 = ( SCAN_MAX_SPAN - 24 - ( hi - lo ) ) / need2;      /* >= 1 */
-                            const uint32_t run2 = runFrom( g2, t2 );
-                            if ( m2 > run2 ) m2 = run2;
-                            const uint32_t rows2 = pc_round_rows( ( hi - lo + m2 * need2 + 24 + 63 ) >> 6 );
-                            const uint32_t base2 = p + lo;     /* the next unit starts in [p + lo, p + hi] */
-                            if ( rows2 <= SCAN_ROWS && base2 + SCAN_MAX_SPAN + 32 <= sizeBits ) {
-                                produce( s ^ 1u, t2, base2, rows2, false );
-                                ahead.table = t2; ahead.base = base2; ahead.rows = rows2; ahead.valid = 1;
-                            }
-                        }
-                    }
-                }
-                if ( lane == 0 ) next.info = ahead;
-            }
-            __syncthreads();
-        }
-        if ( wave == 0 && ( nGroups & 63u ) != 0 && lane < ( nGroups & 63u ) ) gpos[( nGroups & ~63u ) + lane] = gposV;
-    }
-
-    if ( wave == 0 && lane == 0 ) {
-        const uint32_t fullGroups = terminal ? nGroups - 1 : nGroups;
-        BlockMeta mt;
-        mt.enc_off = start;
-        mt.enc_size = sh.hdr.enc_size;
-        mt.decoded_size = 0;
-        mt.out_off = 0;
-        mt.header_crc = sh.hdr.header_crc;
-        mt.computed_crc = 0xFFFFFFFFu;
-        mt.n = 0;
-        mt.orig_ptr = sh.hdr.orig_ptr;
-        mt.nsym = fullGroups * GROUP_SYMS;    /* k_hsym's last lane finishes nsym, enc_size and status of a terminal group */
-        mt.is_eos = sh.hdr.is_eos;
-        mt.is_eof = sh.hdr.is_eof;
-        mt.status = status;
-        mt.seg_stride = MIN_SEG_STRIDE;
-        mt.nseg = 0;
-        mt.walk_ok = 0;
-        mt.cycle_len = 0;
-        mt.nchain = 0;
-        mt.pad = 0;
-        meta[b] = mt;
-        HuffMeta hm;
-        hm.n_stored = fullGroups * GROUP_SYMS;
-        hm.symbol_count = sh.hdr.symbol_count;
-        hm.status = status;
-        hm.active = active;
-        hmeta[b] = hm;
-        ScanMeta sm;
-        sm.pos_base = posBase;
-        sm.size_bits = sizeBits;
-        sm.n_groups = nGroups;
-        sm.terminal = terminal;
-        sm.symbol_count = sh.hdr.symbol_count;
-        sm.pad[0] = sm.pad[1] = 0;
         smeta[b] = sm;
     }
 }

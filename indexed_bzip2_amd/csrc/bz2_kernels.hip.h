@@ -4,7 +4,7 @@
  * Pipeline for one batch of independent bzip2 blocks (reference: one BZ2BlockFetcher::decodeBlock call per block,
  * src/indexed_bzip2/BZ2BlockFetcher.hpp:85-138):
  *
- *   k_huff, k_mtf (bz2_stage1.hip.h)  header, tables, Huffman, RUNA/RUNB, MTF -> L column (u8[N])   bzip2.hpp:479-807
+ *   k_hscan, k_hsym (bz2_hscan.hip.h), k_mtf (bz2_stage1.hip.h)  header, tables, Huffman, RUNA/RUNB, MTF -> L column (u8[N])   bzip2.hpp:479-807
  *   k_bwt_build   per block: byte histogram, stable ranks -> packed LF table u32[N] = LF<<8 | byte | MARK
  *                 (coalesced writes; replaces the scatter of prepare(), bzip2.hpp:810-847)
  *   k_walk, k_link2, k_emit (bz2_walk.hip.h)  multi-segment form of the N-step walk  bzip2.hpp:872-879
@@ -28,9 +28,6 @@ constexpr uint32_t TAB_STRIDE = 1u << 20;     /* u32 entries per block: every 20
 constexpr uint32_t KMAX = 32768;              /* max regular walk segments per block (+1 for origPtr) */
 constexpr uint32_t SEG_STRIDE = KMAX + 64;
 constexpr uint32_t MIN_SEG_STRIDE = 16;
-constexpr int LUT_BITS = 8;    /* index bits of the k_huff look-up tables: 9 makes k_huff itself 8 % faster (57 vs 61.5 ms) but
-                                  its 20 KB of LDS per wave instead of 14 KB cost the co-running kernels more (93 vs 91 ms
-                                  per step); 10 -> 108 ms, 7 -> every window meets a long code */
 constexpr uint32_t MARK = 0x80000000u;
 constexpr uint32_t LF_MASK = 0xFFFFFu;
 constexpr uint32_t INVALID_OFF = 0xFFFFFFFFu;

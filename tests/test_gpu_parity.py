@@ -491,36 +491,31 @@ def bench_slice(native):
     return _slice["v"]
 
 
-@pytest.mark.parametrize("variant", ["scan-pc", "scan-1", "scan-2", "scan-4", "scan-8", "spec-4", "spec-8", "window", "mtf-256",
-                                     "segments-long", "regs-2", "regs-5", "sym-256", "sym-512"])
+@pytest.mark.parametrize("variant", ["scan-1", "spec-4", "spec-8", "mtf-256", "segments-long", "regs-2", "regs-5", "sym-128", "sym-512"])
 def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
-    """Every form of the Huffman stage -- k_hscan_pc, k_hscan with 1, 2, 4 or 8 wavefronts per block, k_hscan_spec with 4 or 8
-    (+ k_hsym) and the single-chain k_huff -- against the oracle, whatever the batch size would select by itself: valid data of all kinds, streams no
-    libbz2 writes, one invalid stream per reference throw site, and seeded damage (every field of every record)."""
-    if variant == "window":
-        monkeypatch.setenv("MI355X_BZ2_HUFF", "window")
+    """Every kernel variant that a batch size or a tuning knob can select -- k_hscan<1> (one wavefront per block) with each of
+    its register budgets, k_hscan_spec with 4 or 8 wavefronts per block, k_hsym with 128 / 256 / 512 groups per workgroup, the
+    256-lane k_mtf instances with each register budget, long walk segments -- against the oracle, whatever the batch size would
+    select by itself: valid data of all kinds, streams no libbz2 writes, one invalid stream per reference throw site, and
+    seeded damage (every field of every record)."""
+    if variant == "mtf-256":
+        # the 256-lane k_mtf instances, which batches of more than 256 blocks use (small batches take the 512-lane ones)
+        monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     elif variant == "segments-long":
-        # what batches of 512 blocks and more use: a quarter of the walk segments, 512 stashed bytes each, with the kernels
-        # of big batches (one scan wave per block, 256-lane k_mtf)
+        # a quarter of the walk segments, 512 stashed bytes each (a measured alternative for big batches), with the kernels of
+        # big batches (one scan wave per block, 256-lane k_mtf)
         monkeypatch.setenv("MI355X_BZ2_SEGMENTS", "long")
         monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1")
         monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     elif variant.startswith("regs-") or variant.startswith("sym-"):
         # the other register budgets of k_hscan<1> / k_mtf / k_link2 and the other workgroup sizes of k_hsym
         monkeypatch.setenv("MI355X_BZ2_REGS", {"regs-2": "scan=2,mtf=2,link=2", "regs-5": "scan=5,mtf=3,link=4",
-                                               "sym-256": "sym=256", "sym-512": "sym=512"}[variant])
+                                               "sym-128": "sym=128", "sym-512": "sym=512"}[variant])
         monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1")
         monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
-    elif variant == "mtf-256":
-        # the 256-lane k_mtf instances, which batches of more than 256 blocks use (small batches take the 512-lane ones)
-        monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     else:
-        # scan-pc: producer + consumer wave per block (k_hscan_pc), scan-N: N cooperating waves (k_hscan<N>),
-        # spec-N: N waves on N consecutive groups (k_hscan_spec<N>)
-        monkeypatch.setenv("MI355X_BZ2_HUFF", "scan")
-        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1" if variant == "scan-pc" else variant.split("-")[1])
-        monkeypatch.setenv("MI355X_BZ2_SCAN_PC", "1" if variant == "scan-pc" else "0")
-        monkeypatch.setenv("MI355X_BZ2_SCAN_SPEC", "1" if variant.startswith("spec") else "0")
+        # scan-1: k_hscan<1>; spec-N: N waves on N consecutive groups (k_hscan_spec<N>)
+        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", variant.split("-")[1])
     d = native.Decoder(flags=native.Decoder.KEEP_STAGES)
     try:
         corpus = datagen.corpus_small()

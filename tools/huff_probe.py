@@ -1,5 +1,5 @@
 """Developer probe: stage-1 variants side by side -- single blocks, a 320-block batch, the whole 2 560-block batch.
-Prints wall time per batch and the per-kernel event durations (k_hscan / k_hsym / k_huff / k_mtf)."""
+Prints wall time per batch and the per-kernel event durations (k_hscan / k_hsym / k_mtf)."""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ import indexed_bzip2_amd as m
 
 
 def main():
-    modes = sys.argv[1:] or ["scan", "window"]
+    modes = sys.argv[1:] or ["scan"]
     path, enc, meta = bench.build_workload(2 * 1024**3, 214_748_364, "/tmp/indexed_bzip2_amd_bench", 0, 1, lambda: None)
     offsets = meta["offsets"]
     sizes = [(b - a, i) for i, (a, b) in enumerate(zip(offsets, offsets[1:]))]
