@@ -127,6 +127,34 @@ for_symbols( const uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
     }
 }
 
+/** The same walk over symbols [begin, end), but every symbol is REPLACED by what step( symbol ) returns (a u16): the groups of
+ * eight go back as one 16-byte store. */
+template<typename Step>
+__device__ __forceinline__ void
+rewrite_symbols( uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
+{
+    uint32_t i = begin;
+    for ( ; i < end && ( i & 7u ) != 0; ++i ) sym[i] = (uint16_t)step( (uint32_t)sym[i] );
+    if ( i + 8 <= end ) {
+        uint4 next = *reinterpret_cast<const uint4*>( sym + i );
+        for ( ; i + 8 <= end; i += 8 ) {
+            const uint4 v = next;
+            next = *reinterpret_cast<const uint4*>( sym + i + 8 );   /* the symbol buffer is padded past n */
+            uint4 r;
+            r.x = step( v.x & 0xFFFFu );
+            r.x |= step( v.x >> 16 ) << 16;
+            r.y = step( v.y & 0xFFFFu );
+            r.y |= step( v.y >> 16 ) << 16;
+            r.z = step( v.z & 0xFFFFu );
+            r.z |= step( v.z >> 16 ) << 16;
+            r.w = step( v.w & 0xFFFFu );
+            r.w |= step( v.w >> 16 ) << 16;
+            *reinterpret_cast<uint4*>( sym + i ) = r;
+        }
+    }
+    for ( ; i < end; ++i ) sym[i] = (uint16_t)step( (uint32_t)sym[i] );
+}
+
 /** Per-lane write combiner for a sequential byte stream: whole aligned dwords go out as one store (byte-granular
  * scattered stores cost a full write request each: 43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE).  Only the
  * unaligned head and the tail of a lane's range, which share a dword with the neighbouring lane, are written bytewise.
@@ -223,7 +251,7 @@ template<uint32_t LANE_STRIDE, uint32_t THREADS>
 __device__ __forceinline__ void
 mtf_block( BlockMeta* __restrict__       meta,
            const HuffMeta* __restrict__  hmeta,
-           const uint16_t* __restrict__  sym_buf,
+           uint16_t* __restrict__        sym_buf,
            const uint8_t* __restrict__   stb_buf,
            uint8_t* __restrict__         l_buf,
            uint32_t                      n_blocks,
@@ -237,6 +265,13 @@ mtf_block( BlockMeta* __restrict__       meta,
            uint32_t* __restrict__        firstErrorAt )
 {
     constexpr uint32_t LIST_ENTRIES = LANE_STRIDE - 16;
+    /* How pass B gets its bytes.  Lists of up to 128 entries (text): the moves are replayed on the true start list -- they are
+     * 0.1 ms of a pass there.  Lists of 256 entries (binary and incompressible data, whose moves shift 128 bytes of a lane's
+     * list on average: the kernel is bound by the LDS traffic of that, 43 ms for 2 620 incompressible blocks): pass A leaves
+     * behind, in place of every symbol, the POSITION its entry has in the chunk's start list (the list starts as the identity,
+     * so that is what a move brings to the front), and pass B only looks positions up -- half the list traffic for 1.8 MB of
+     * symbols written back per block. */
+    constexpr bool REPLAY = LANE_STRIDE == MTF_SMALL_STRIDE;
     uint32_t& firstError = *firstErrorAt;
 
     const uint32_t slot = blockIdx.x;
@@ -247,7 +282,7 @@ mtf_block( BlockMeta* __restrict__       meta,
     if ( ( hm.symbol_count <= MTF_SMALL_STRIDE - 16 ) != ( LANE_STRIDE == MTF_SMALL_STRIDE ) ) return;   /* other instance */
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t n = hm.n_stored;
-    const uint16_t* const sym = sym_buf + (size_t)b * SYM_STRIDE;
+    uint16_t* const sym = sym_buf + (size_t)b * SYM_STRIDE;
     uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
     uint4* const mine = reinterpret_cast<uint4*>( listBytes + t * LANE_STRIDE );
 
@@ -273,18 +308,22 @@ mtf_block( BlockMeta* __restrict__       meta,
     unsigned long long count = 0;
     {
         uint32_t runPos = 0, hh = 0;
-        for_symbols( sym, begin, end, [&] ( uint32_t s ) {
+        const auto one = [&] ( uint32_t s ) -> uint32_t {
             if ( s <= 1 ) {
                 if ( runPos == 0 ) { runPos = 1; hh = 0; }
                 hh += runPos << s;
                 runPos <<= 1;
-            } else {
-                if ( runPos != 0 ) { count += hh; runPos = 0; }
-                mtf_lane_move( mine, permRows, s - 1 );
-                ++count;
+                return s;
             }
-            return true;
-        } );
+            if ( runPos != 0 ) { count += hh; runPos = 0; }
+            ++count;
+            return mtf_lane_move( mine, permRows, s - 1 ) + 2u;    /* (run digits stay 0 and 1) */
+        };
+        if constexpr ( REPLAY ) {
+            for_symbols( sym, begin, end, [&] ( uint32_t s ) { (void)one( s ); return true; } );
+        } else {
+            rewrite_symbols( sym, begin, end, one );
+        }
         if ( runPos != 0 ) count += hh;
     }
     /* exclusive prefix sum of the chunk sizes */
@@ -316,14 +355,14 @@ mtf_block( BlockMeta* __restrict__       meta,
         __syncthreads();
     }
 
-    /* ---- pass B: replay with the true start list, write the L column.  (Round 3 measured the alternative -- pass A replaces
-     * every symbol by the position its entry has in the chunk's start list, pass B only looks positions up: the list updates
-     * of a pass cost 0.1 to 1.4 ms of its 3.3 ms, the rewritten symbols 4.6 GB of writes; no gain, profiles/r03_mtf_probe.txt) ---- */
+    /* ---- pass B: the chunk again with its true start list, the L column written ---- */
     {
         /* positions are 32-bit: a start beyond the buffer (only possible for damaged data, whose runs can add up to
          * anything) is clamped -- that lane then reports the overflow at its first symbol, an earlier lane wins anyway */
         const uint32_t startAt = prefix < MAX_N ? (uint32_t)prefix : MAX_N;
         ByteSink sink{ L, startAt, startAt, 0 };
+        const uint8_t* const list = reinterpret_cast<const uint8_t*>( mine );
+        uint32_t front = 0;       /* !REPLAY: position (in the start list) of the entry that is at the front now */
         uint32_t runPos = 0, hh = 0;
         uint32_t err = 0;
         for_symbols( sym, begin, end, [&] ( uint32_t s ) {
@@ -336,10 +375,15 @@ mtf_block( BlockMeta* __restrict__       meta,
             if ( runPos != 0 ) {
                 runPos = 0;
                 if ( sink.o + hh > MAX_N ) { err = ST_RUN_OVERFLOW; return false; }
-                sink.fill( reinterpret_cast<const uint8_t*>( mine )[0], hh );
+                sink.fill( list[REPLAY ? 0u : front], hh );
             }
             if ( sink.o >= MAX_N ) { err = ST_DATA_OVERFLOW; return false; }
-            sink.put( mtf_lane_move( mine, permRows, s - 1 ) );
+            if constexpr ( REPLAY ) {
+                sink.put( mtf_lane_move( mine, permRows, s - 1 ) );
+            } else {
+                front = s - 2u;
+                sink.put( list[front] );
+            }
             return true;
         } );
         /* a run that is still open where the Huffman stage FAILED is never flushed by the reference */
@@ -347,7 +391,7 @@ mtf_block( BlockMeta* __restrict__       meta,
             if ( sink.o + hh > MAX_N ) {
                 err = ST_RUN_OVERFLOW;
             } else {
-                sink.fill( reinterpret_cast<const uint8_t*>( mine )[0], hh );
+                sink.fill( list[REPLAY ? 0u : front], hh );
             }
         }
         sink.flush();
@@ -379,7 +423,7 @@ template<uint32_t LANE_STRIDE, uint32_t THREADS = MTF_THREADS, uint32_t W = 2>
 __global__ __launch_bounds__( THREADS ) __attribute__( ( amdgpu_waves_per_eu( W, 8 ) ) ) void
 k_mtf( BlockMeta* __restrict__       meta,
        const HuffMeta* __restrict__  hmeta,
-       const uint16_t* __restrict__  sym_buf,
+       uint16_t* __restrict__        sym_buf,       /* the <272> instance rewrites it in place, see mtf_block */
        const uint8_t* __restrict__   stb_buf,
        uint8_t* __restrict__         l_buf,
        uint32_t                      n_blocks,
