@@ -141,7 +141,6 @@ struct mi355x_bz2_ctx
     uint8_t* dR{ nullptr };
     uint32_t* dSegLen{ nullptr };
     uint32_t* dSegSucc{ nullptr };
-    uint32_t* dSegOff{ nullptr };
     uint32_t* dSegCont{ nullptr };    /* [cap][SEG_STRIDE]: where a segment longer than STASH_BYTES goes on */
     uint4*    dChain{ nullptr };      /* [cap][SEG_STRIDE]: segments in cycle order {segment, offset, length, continuation} */
     uint32_t* dStash{ nullptr };      /* [cap][SEG_STRIDE][STASH_BYTES / 4]: first bytes of every segment */
@@ -281,7 +280,7 @@ freeScratch( mi355x_bz2_ctx* c, bool now = true )
     c->scratchBytes = c->scratchHostBytes = 0;
     c->dOffsets = nullptr; c->dOrder = nullptr; c->dMeta = nullptr; c->dSel = nullptr; c->dSym = nullptr; c->dStb = nullptr;
     c->dHmeta = nullptr; c->dSmeta = nullptr; c->dHtab = nullptr; c->dGpos = nullptr; c->dL = nullptr; c->dTab = nullptr;
-    c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegOff = nullptr; c->dSegCont = nullptr;
+    c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegCont = nullptr;
     c->dChain = nullptr; c->dStash = nullptr; c->dPlan = nullptr; c->dWalkBlk = nullptr; c->dWalkPre = nullptr;
     c->hOrder = nullptr; c->hSlotOf = nullptr; c->hMeta = nullptr; c->hOffsets = nullptr;
     c->dSlotOf = nullptr; c->dTotals = nullptr; c->hTotals = nullptr; c->dScanQueue = nullptr;
@@ -322,7 +321,6 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t oR = reserve( deviceBytes, (size_t)cap * L_STRIDE + 256 );
     const size_t oSegLen = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
     const size_t oSegSucc = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
-    const size_t oSegOff = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
     const size_t oSegCont = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
     const size_t oChain = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint4 ) );
     const size_t oStash = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * STASH_BYTES );
@@ -362,7 +360,6 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dR = d + oR;
     c->dSegLen = reinterpret_cast<uint32_t*>( d + oSegLen );
     c->dSegSucc = reinterpret_cast<uint32_t*>( d + oSegSucc );
-    c->dSegOff = reinterpret_cast<uint32_t*>( d + oSegOff );
     c->dSegCont = reinterpret_cast<uint32_t*>( d + oSegCont );
     c->dChain = reinterpret_cast<uint4*>( d + oChain );
     c->dStash = reinterpret_cast<uint32_t*>( d + oStash );
@@ -1081,7 +1078,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                                ? (uint32_t)std::atoi( wg )
                                : ( crowd ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
-    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
+    /* segments per claim: a big batch has millions of them (a claim of 1 024 costs a quarter of the barriers and counter
+     * updates: k_walk 22.1 -> 19.1 ms for the bench's batch with 64 workgroups per XCD), a lone block's 32 768 have to be
+     * spread over all workgroups */
+    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : ( n >= 64 ? 4 * WALK_CHUNK : WALK_CHUNK );
 
     const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: 1 = k_hscan<1>, 4 / 8 = k_hscan_spec<4 / 8>, whatever the batch size */
     const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;
@@ -1133,7 +1133,6 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         uint8_t* const rbuf = c->dR + (size_t)first * L_STRIDE;
         uint32_t* const segLen = c->dSegLen + (size_t)first * SEG_STRIDE;
         uint32_t* const segSucc = c->dSegSucc + (size_t)first * SEG_STRIDE;
-        uint32_t* const segOff = c->dSegOff + (size_t)first * SEG_STRIDE;
         uint32_t* const segCont = c->dSegCont + (size_t)first * SEG_STRIDE;
         uint4* const chain = c->dChain + (size_t)first * SEG_STRIDE;
         uint32_t* const stash = c->dStash + (size_t)first * SEG_STRIDE * ( STASH_BYTES / 4 );
@@ -1259,9 +1258,9 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             }
         }
         if ( regs.link >= 4 ) {
-            TIMED_LAUNCH( c, g, q, 4, k_link2<4>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, segOff, chain, stashBytes );
+            TIMED_LAUNCH( c, g, q, 4, k_link2<4>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, chain, stashBytes );
         } else {
-            TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, segOff, chain, stashBytes );
+            TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, chain, stashBytes );
         }
         if ( longSegments ) {
             TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES_LONG>, dim3( ( KMAX / 4 + 2 + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,

@@ -107,7 +107,6 @@ link_block( BlockMeta*                   meta,
             const uint32_t* __restrict__ seg_len,
             const uint32_t* __restrict__ seg_succ,
             const uint32_t* __restrict__ seg_cont,
-            uint32_t* __restrict__       seg_off,
             uint4* __restrict__          chain,
             uint32_t                     stash_bytes,
             uint16_t* __restrict__       ssucc,
@@ -129,7 +128,6 @@ link_block( BlockMeta*                   meta,
     for ( uint32_t j = tid; j < nseg; j += LINK_THREADS ) {
         const uint32_t s = seg_succ[base + j];
         ssucc[j] = (uint16_t)( s < nseg ? s : 0xFFFFu );
-        seg_off[base + j] = INVALID_OFF;
     }
     /* sub-chain s < nSplit starts at segment s * LINK_SPLIT; sub-chain nSplit starts at `first` (unless that is a
      * multiple of LINK_SPLIT already) */
@@ -143,17 +141,36 @@ link_block( BlockMeta*                   meta,
     for ( uint32_t s = tid; s < LINK_MAX_SUB; s += LINK_THREADS ) subOff[s] = INVALID_OFF;
     __syncthreads();
 
-    /* pass 1: length and successor of every sub-chain */
+    /* pass 1: length and successor of every sub-chain.  The chain itself runs through LDS; the segment lengths come from
+     * memory, eight at a time: one load per step of the chain made every step wait for memory (4.6 ms for the bench's batch
+     * with one wait per step). */
+    constexpr uint32_t AHEAD = 8;
     for ( uint32_t s = tid; s < nSub; s += LINK_THREADS ) {
         uint32_t cur = s < nSplit ? s * LINK_SPLIT : first;
         uint32_t sum = 0, steps = 0, nextSub = 0xFFFFu;
-        for ( ;; ) {
-            sum += seg_len[base + cur];
-            cur = ssucc[cur];
-            ++steps;
-            if ( cur == 0xFFFFu || steps > nseg ) break;           /* broken chain (cannot happen for a permutation) */
-            nextSub = splitterOf( cur );
-            if ( nextSub != 0xFFFFu ) break;
+        bool more = true;
+        while ( more ) {
+            uint32_t nodes[AHEAD];
+            uint32_t m = 0;
+#pragma unroll
+            for ( uint32_t k = 0; k < AHEAD; ++k ) {
+                nodes[k] = cur;
+                if ( more ) {
+                    m = k + 1;
+                    cur = ssucc[cur];
+                    ++steps;
+                    if ( cur == 0xFFFFu || steps > nseg ) {
+                        more = false;                                   /* broken chain (cannot happen for a permutation) */
+                    } else {
+                        nextSub = splitterOf( cur );
+                        more = nextSub == 0xFFFFu;
+                    }
+                }
+            }
+#pragma unroll
+            for ( uint32_t k = 0; k < AHEAD; ++k ) {
+                if ( k < m ) sum += seg_len[base + nodes[k]];
+            }
         }
         subLen[s] = sum;
         subCnt[s] = steps;
@@ -184,24 +201,40 @@ link_block( BlockMeta*                   meta,
     }
     __syncthreads();
 
-    /* pass 2: offsets of the segments of every sub-chain that lies on the cycle */
+    /* pass 2: offsets of the segments of every sub-chain that lies on the cycle (lengths eight at a time, as above) */
     for ( uint32_t s = tid; s < nSub; s += LINK_THREADS ) {
         uint32_t off = subOff[s];
         if ( off == INVALID_OFF ) continue;
         uint32_t cur = s < nSplit ? s * LINK_SPLIT : first;
         uint32_t steps = 0;
         uint32_t rank = subRank[s];
-        for ( ;; ) {
-            const uint32_t len = seg_len[base + cur];
-            seg_off[base + cur] = off;
-            /* record for k_emit, in cycle order: segment, output offset, length, where its walk goes on after the
-             * stash_bytes the first pass kept */
-            chain[base + rank] = make_uint4( cur, off, len, len > stash_bytes ? seg_cont[base + cur] : 0u );
-            ++rank;
-            off += len;
-            cur = ssucc[cur];
-            ++steps;
-            if ( cur == 0xFFFFu || steps > nseg || splitterOf( cur ) != 0xFFFFu ) break;
+        bool more = true;
+        while ( more ) {
+            uint32_t nodes[AHEAD], lens[AHEAD];
+            uint32_t m = 0;
+#pragma unroll
+            for ( uint32_t k = 0; k < AHEAD; ++k ) {
+                nodes[k] = cur;
+                if ( more ) {
+                    m = k + 1;
+                    cur = ssucc[cur];
+                    ++steps;
+                    more = !( cur == 0xFFFFu || steps > nseg || splitterOf( cur ) != 0xFFFFu );
+                }
+            }
+#pragma unroll
+            for ( uint32_t k = 0; k < AHEAD; ++k ) lens[k] = k < m ? seg_len[base + nodes[k]] : 0u;
+#pragma unroll
+            for ( uint32_t k = 0; k < AHEAD; ++k ) {
+                if ( k < m ) {
+                    const uint32_t len = lens[k];
+                    /* record for k_emit, in cycle order: segment, output offset, length, where its walk goes on after the
+                     * stash_bytes the first pass kept */
+                    chain[base + rank] = make_uint4( nodes[k], off, len, len > stash_bytes ? seg_cont[base + nodes[k]] : 0u );
+                    ++rank;
+                    off += len;
+                }
+            }
         }
     }
 }
@@ -213,13 +246,12 @@ k_link2( BlockMeta*                   meta,
          const uint32_t* __restrict__ seg_len,
          const uint32_t* __restrict__ seg_succ,
          const uint32_t* __restrict__ seg_cont,
-         uint32_t* __restrict__       seg_off,
          uint4* __restrict__          chain,
          uint32_t                     stash_bytes )   /* what k_walk kept of every segment */
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( LinkShared ) */
     auto& shared = *reinterpret_cast<LinkShared*>( ldsAtLaunch );
-    link_block( meta, seg_len, seg_succ, seg_cont, seg_off, chain, stash_bytes, shared.ssucc, shared.subLen, shared.subNext, shared.subOff,
+    link_block( meta, seg_len, seg_succ, seg_cont, chain, stash_bytes, shared.ssucc, shared.subLen, shared.subNext, shared.subOff,
                 shared.subCnt, shared.subRank );
 }
 
