@@ -142,7 +142,7 @@ struct mi355x_bz2_ctx
     uint32_t* dSegLen{ nullptr };
     uint32_t* dSegSucc{ nullptr };
     uint32_t* dSegCont{ nullptr };    /* [cap][SEG_STRIDE]: where a segment longer than STASH_BYTES goes on */
-    uint4*    dChain{ nullptr };      /* [cap][SEG_STRIDE]: segments in cycle order {segment, offset, length, continuation} */
+    uint2*    dChain{ nullptr };      /* [cap][SEG_STRIDE]: segments in cycle order {offset, length, segment} */
     uint32_t* dStash{ nullptr };      /* [cap][SEG_STRIDE][STASH_BYTES / 4]: first bytes of every segment */
     WalkPlan* dPlan{ nullptr };       /* [MAX_GROUPS]: one per group */
     uint32_t* dWalkBlk{ nullptr };    /* [MAX_GROUPS][cap + 16] */
@@ -322,7 +322,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t oSegLen = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
     const size_t oSegSucc = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
     const size_t oSegCont = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint32_t ) );
-    const size_t oChain = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint4 ) );
+    const size_t oChain = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * sizeof( uint2 ) );
     const size_t oStash = reserve( deviceBytes, (size_t)cap * SEG_STRIDE * STASH_BYTES );
     const size_t oPlan = reserve( deviceBytes, MAX_GROUPS * sizeof( WalkPlan ) );
     const size_t oWalkBlk = reserve( deviceBytes, MAX_GROUPS * ( (size_t)cap + 16 ) * sizeof( uint32_t ) );
@@ -361,7 +361,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dSegLen = reinterpret_cast<uint32_t*>( d + oSegLen );
     c->dSegSucc = reinterpret_cast<uint32_t*>( d + oSegSucc );
     c->dSegCont = reinterpret_cast<uint32_t*>( d + oSegCont );
-    c->dChain = reinterpret_cast<uint4*>( d + oChain );
+    c->dChain = reinterpret_cast<uint2*>( d + oChain );
     c->dStash = reinterpret_cast<uint32_t*>( d + oStash );
     c->dPlan = reinterpret_cast<WalkPlan*>( d + oPlan );
     c->dWalkBlk = reinterpret_cast<uint32_t*>( d + oWalkBlk );
@@ -1109,7 +1109,6 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     bool longSegments = false;   /* measured slower for the bench's batch (k_link2 4.7 -> 1.8 ms, but k_walk 21 -> 32, k_emit 5.3 -> 10.8) */
     if ( const char* sg2 = std::getenv( "MI355X_BZ2_SEGMENTS" ) ) longSegments = sg2[0] == 'l';
     const uint32_t segTarget = longSegments ? KMAX / 4 : KMAX;
-    const uint32_t stashBytes = longSegments ? STASH_BYTES_LONG : STASH_BYTES;
     const char* smx = std::getenv( "MI355X_BZ2_SCAN_MIXED" );   /* 0: off; 4 / 8: that many waves per expensive block; default: by count */
     const uint32_t scanMixed = smx != nullptr ? (uint32_t)std::atoi( smx ) : 1u;
     const char* wsr = std::getenv( "MI355X_BZ2_WALK_SERIAL" );
@@ -1134,7 +1133,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         uint32_t* const segLen = c->dSegLen + (size_t)first * SEG_STRIDE;
         uint32_t* const segSucc = c->dSegSucc + (size_t)first * SEG_STRIDE;
         uint32_t* const segCont = c->dSegCont + (size_t)first * SEG_STRIDE;
-        uint4* const chain = c->dChain + (size_t)first * SEG_STRIDE;
+        uint2* const chain = c->dChain + (size_t)first * SEG_STRIDE;
         uint32_t* const stash = c->dStash + (size_t)first * SEG_STRIDE * ( STASH_BYTES / 4 );
         const uint32_t* const order = c->dOrder + first;
         WalkPlan* const plan = c->dPlan + g;
@@ -1258,16 +1257,16 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             }
         }
         if ( regs.link >= 4 ) {
-            TIMED_LAUNCH( c, g, q, 4, k_link2<4>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, chain, stashBytes );
+            TIMED_LAUNCH( c, g, q, 4, k_link2<4>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
         } else {
-            TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, segCont, chain, stashBytes );
+            TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
         }
         if ( longSegments ) {
             TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES_LONG>, dim3( ( KMAX / 4 + 2 + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
-                          meta, tab, chain, stash, rbuf );
+                          meta, tab, chain, stash, segCont, rbuf );
         } else {
             TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES>, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
-                          meta, tab, chain, stash, rbuf );
+                          meta, tab, chain, stash, segCont, rbuf );
         }
         TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, lcol );
         TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );

@@ -106,9 +106,7 @@ __device__ __forceinline__ void
 link_block( BlockMeta*                   meta,
             const uint32_t* __restrict__ seg_len,
             const uint32_t* __restrict__ seg_succ,
-            const uint32_t* __restrict__ seg_cont,
-            uint4* __restrict__          chain,
-            uint32_t                     stash_bytes,
+            uint2* __restrict__          chain,
             uint16_t* __restrict__       ssucc,
             uint32_t* __restrict__       subLen,
             uint16_t* __restrict__       subNext,
@@ -228,9 +226,8 @@ link_block( BlockMeta*                   meta,
             for ( uint32_t k = 0; k < AHEAD; ++k ) {
                 if ( k < m ) {
                     const uint32_t len = lens[k];
-                    /* record for k_emit, in cycle order: segment, output offset, length, where its walk goes on after the
-                     * stash_bytes the first pass kept */
-                    chain[base + rank] = make_uint4( nodes[k], off, len, len > stash_bytes ? seg_cont[base + nodes[k]] : 0u );
+                    /* record for k_emit, in cycle order: output offset and length (20 bits each), segment (16 bits) */
+                    chain[base + rank] = make_uint2( off | ( nodes[k] << 20 ), len | ( ( nodes[k] >> 12 ) << 20 ) );
                     ++rank;
                     off += len;
                 }
@@ -245,13 +242,11 @@ __global__ __launch_bounds__( LINK_THREADS ) __attribute__( ( amdgpu_waves_per_e
 k_link2( BlockMeta*                   meta,
          const uint32_t* __restrict__ seg_len,
          const uint32_t* __restrict__ seg_succ,
-         const uint32_t* __restrict__ seg_cont,
-         uint4* __restrict__          chain,
-         uint32_t                     stash_bytes )   /* what k_walk kept of every segment */
+         uint2* __restrict__          chain )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( LinkShared ) */
     auto& shared = *reinterpret_cast<LinkShared*>( ldsAtLaunch );
-    link_block( meta, seg_len, seg_succ, seg_cont, chain, stash_bytes, shared.ssucc, shared.subLen, shared.subNext, shared.subOff,
+    link_block( meta, seg_len, seg_succ, chain, shared.ssucc, shared.subLen, shared.subNext, shared.subOff,
                 shared.subCnt, shared.subRank );
 }
 
@@ -400,8 +395,9 @@ template<uint32_t STASH = STASH_BYTES, uint32_t STAGE = ( STASH <= 128 ? EMIT_ST
 __global__ __launch_bounds__( EMIT_THREADS ) void
 k_emit( const BlockMeta* __restrict__ meta,
         const uint32_t* __restrict__  tab_buf,
-        const uint4* __restrict__     chain,
+        const uint2* __restrict__     chain,
         const uint32_t* __restrict__  stash,
+        const uint32_t* __restrict__  seg_cont,   /* table index of byte STASH of a longer segment */
         uint8_t* __restrict__         r_buf )
 {
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t image[STAGE + 16];
@@ -418,9 +414,9 @@ k_emit( const BlockMeta* __restrict__ meta,
     uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
     const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
 
-    uint4 rec = make_uint4( 0, 0, 0, 0 );
+    uint2 rec = make_uint2( 0, 0 );
     if ( t < count ) rec = chain[base + r0 + t];
-    const uint32_t seg = rec.x, off = rec.y, len = rec.z;
+    const uint32_t off = rec.x & 0xFFFFFu, len = rec.y & 0xFFFFFu, seg = ( rec.x >> 20 ) | ( ( rec.y >> 20 ) << 12 );
     /* the piece: [low, top], top = address of the first byte of the first segment */
     __shared__ uint32_t sTop;
     if ( t == count - 1 ) sLow = N - off - len;           /* N - 1 - (off + len - 1) */
@@ -454,7 +450,7 @@ k_emit( const BlockMeta* __restrict__ meta,
             for ( uint32_t quad = 0; quad * 16 < kept; ++quad ) sixteen( quad );
         }
         if ( len > STASH ) {
-            uint32_t p = rec.w;
+            uint32_t p = seg_cont[base + seg];
             a -= STASH;
             for ( uint32_t i = STASH; i < len; ++i ) {
                 const uint32_t e = tab[p];

@@ -30,11 +30,11 @@ pmc() {     # pmc <name> <args...>: FETCH_SIZE and WRITE_SIZE passes
 }
 for w in $WHAT; do
   case $w in
-    default) stats default $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline || exit 1 ;;
-    nosplit) MI355X_BZ2_NO_SPLIT=1 stats nosplit $R/bench.py --steps 3 --warmup 1 --contexts 1 --resident --no-cpu-baseline || exit 1 ;;
-    traffic) pmc bench $R/bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline ;;
-    config3) stats config3 $R/tools/bench_configs.py 3 || exit 1
-             pmc config3 $R/tools/bench_configs.py 3 ;;
+    default) stats default $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-host-output || exit 1 ;;
+    nosplit) MI355X_BZ2_NO_SPLIT=1 stats nosplit $R/bench.py --steps 3 --warmup 1 --contexts 1 --resident --no-cpu-baseline --no-host-output || exit 1 ;;
+    traffic) pmc bench $R/bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --no-host-output ;;
+    config3) MI355X_BZ2_NO_SPLIT=1 stats config3 $R/bench.py --workload urandom --steps 3 --warmup 1 --contexts 1 --resident --no-cpu-baseline --no-host-output || exit 1
+             pmc config3 $R/bench.py --workload urandom --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --no-host-output ;;
   esac
 done
 cd $R
