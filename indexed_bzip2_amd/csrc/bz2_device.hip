@@ -1179,7 +1179,7 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                 if ( regs.scan >= 5 ) { SCAN1( 5 ); } else if ( regs.scan == 4 ) { SCAN1( 4 ); } else { SCAN1( 2 ); }
 #undef SCAN1
             }
-#define HSYM( T ) TIMED_LAUNCH( c, g, q, 13, k_hsym<T>, dim3( ( MAX_SCAN_GROUPS + ( T ) - 1 ) / ( T ), m ), dim3( T ), \
+#define HSYM( T ) TIMED_LAUNCH( c, g, q, 13, k_hsym<T>, dim3( ( MAX_SCAN_GROUPS + ( T ) * SYM_CHUNKS - 1 ) / ( ( T ) * SYM_CHUNKS ), m ), dim3( T ), \
                                 sizeof( SymShared<T> ), q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym )
             if ( regs.sym >= 512 ) { HSYM( 512 ); } else if ( regs.sym >= 256 ) { HSYM( 256 ); } else { HSYM( 128 ); }
 #undef HSYM
@@ -1262,10 +1262,10 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
         }
         if ( longSegments ) {
-            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES_LONG>, dim3( ( KMAX / 4 + 2 + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
+            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES_LONG>, dim3( ( KMAX / 4 + 2 + EMIT_THREADS * EMIT_TILES - 1 ) / ( EMIT_THREADS * EMIT_TILES ), m ), dim3( EMIT_THREADS ), 0, q,
                           meta, tab, chain, stash, segCont, rbuf );
         } else {
-            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES>, dim3( ( SEG_STRIDE + EMIT_THREADS - 1 ) / EMIT_THREADS, m ), dim3( EMIT_THREADS ), 0, q,
+            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES>, dim3( ( SEG_STRIDE + EMIT_THREADS * EMIT_TILES - 1 ) / ( EMIT_THREADS * EMIT_TILES ), m ), dim3( EMIT_THREADS ), 0, q,
                           meta, tab, chain, stash, segCont, rbuf );
         }
         TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, lcol );

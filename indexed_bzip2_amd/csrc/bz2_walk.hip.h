@@ -35,6 +35,7 @@ constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first wal
 constexpr uint32_t STASH_BYTES_LONG = 512;   /* the same for batches whose blocks are cut into KMAX / 4 segments (108 bytes on
                                                 average, 0.9 % of the bytes beyond): same buffer, a quarter of the slots */
 constexpr uint32_t EMIT_THREADS = 256;       /* segments (consecutive along the cycle) per k_emit workgroup */
+constexpr uint32_t EMIT_TILES = 4;           /* such pieces per workgroup, one after the other */
 constexpr uint32_t EMIT_STAGE = 16384;       /* LDS bytes that collect their output before it is written in whole lines */
 
 struct WalkPlan
@@ -400,64 +401,112 @@ k_emit( const BlockMeta* __restrict__ meta,
         const uint32_t* __restrict__  seg_cont,   /* table index of byte STASH of a longer segment */
         uint8_t* __restrict__         r_buf )
 {
+    constexpr uint32_t FIRST = 2;                                /* 16-byte pieces of a segment that its own lane takes */
+    constexpr uint32_t MORE = STASH / 16 - FIRST;                /* further pieces a segment can have in the stash */
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t image[STAGE + 16];
-    __shared__ uint32_t sLow;    /* lowest output address of the piece */
+    __shared__ uint32_t sLow, sTop;                              /* lowest / highest output address of the piece */
+    __shared__ uint32_t segAddr[EMIT_THREADS], segLen[EMIT_THREADS], segId[EMIT_THREADS];
+    __shared__ uint16_t later[STASH <= 128 ? EMIT_THREADS * MORE : 1];   /* pieces behind the first two: lane << 3 | piece */
+    __shared__ uint32_t waveSum[EMIT_THREADS / 64];
     const uint32_t b = blockIdx.y;
     const BlockMeta mt = meta[b];
     if ( !mt.walk_ok ) return;
-    const uint32_t r0 = blockIdx.x * EMIT_THREADS;
-    if ( r0 >= mt.nchain ) return;
     const uint32_t t = threadIdx.x;
     const uint32_t N = mt.n;
+    /* EMIT_TILES pieces of the output per workgroup, one after the other: a workgroup costs about 11 ns of dispatch whatever it
+     * does (k_hsym with 182 000 / 91 000 / 45 000 workgroups: 4.5 / 3.5 / 3.05 ms), and 330 000 workgroups of one piece each
+     * made that 3.5 of this kernel's 5.3 ms */
+    for ( uint32_t tile = 0; tile < EMIT_TILES; ++tile ) {
+    const uint32_t r0 = ( blockIdx.x * EMIT_TILES + tile ) * EMIT_THREADS;
+    if ( r0 >= mt.nchain ) return;
     const uint32_t count = mt.nchain - r0 < EMIT_THREADS ? mt.nchain - r0 : EMIT_THREADS;
     const size_t base = (size_t)b * SEG_STRIDE;
     uint8_t* const R = r_buf + (size_t)b * L_STRIDE;
     const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+    const uint32_t* const stashOfBlock = stash + base * ( STASH_BYTES / 4 );
 
     uint2 rec = make_uint2( 0, 0 );
     if ( t < count ) rec = chain[base + r0 + t];
     const uint32_t off = rec.x & 0xFFFFFu, len = rec.y & 0xFFFFFu, seg = ( rec.x >> 20 ) | ( ( rec.y >> 20 ) << 12 );
     /* the piece: [low, top], top = address of the first byte of the first segment */
-    __shared__ uint32_t sTop;
     if ( t == count - 1 ) sLow = N - off - len;           /* N - 1 - (off + len - 1) */
     if ( t == 0 ) sTop = N - 1 - off;
+    const uint32_t kept = t < count ? ( len < STASH ? len : STASH ) : 0u;
+    const uint32_t addr0 = N - 1 - off;                   /* address of byte 0 */
+    uint32_t laterTotal = 0;
+    if constexpr ( STASH <= 128 ) {
+        /* Segment lengths are geometric (mean 27): a lane that copies ITS segment runs the longest segment's eight pieces with
+         * one lane in five alive (3.5 of k_emit's 5.4 ms for the bench's batch were that skeleton).  So a lane copies the
+         * first two pieces of its segment -- 70 % of the segments end there -- and the pieces behind them are listed and
+         * dealt out to the lanes again. */
+        segAddr[t] = addr0;
+        segLen[t] = kept;
+        segId[t] = seg;
+        const uint32_t pieces = ( kept + 15 ) >> 4;
+        const uint32_t mine = pieces > FIRST ? pieces - FIRST : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for ( int d = 1; d < 64; d <<= 1 ) {
+            const uint32_t o = (uint32_t)__shfl_up( (int)incl, d );
+            if ( (int)( t & 63u ) >= d ) incl += o;
+        }
+        if ( ( t & 63u ) == 63u ) waveSum[t >> 6] = incl;
+        __syncthreads();
+        uint32_t start = incl - mine;
+#pragma unroll
+        for ( uint32_t w = 0; w < EMIT_THREADS / 64; ++w ) {
+            if ( w < ( t >> 6 ) ) start += waveSum[w];
+            laterTotal += waveSum[w];
+        }
+#pragma unroll
+        for ( uint32_t k = 0; k < MORE; ++k ) {
+            if ( k < mine ) later[start + k] = (uint16_t)( ( t << 3 ) | ( FIRST + k ) );
+        }
+    }
     __syncthreads();
     const uint32_t low = sLow, top = sTop;
     const uint32_t imageBase = low & ~15u;                /* the image mirrors memory from a 16-byte boundary */
 
-    if ( t < count ) {
-        const uint32_t kept = len < STASH ? len : STASH;
-        const uint4* const line = reinterpret_cast<const uint4*>( stash + base * ( STASH_BYTES / 4 ) + (size_t)seg * ( STASH / 4 ) );
-        uint32_t a = N - 1 - off;                         /* address of byte 0 */
-        const auto put = [&] ( uint32_t addr, uint32_t byte ) {
-            const uint32_t pos = addr - imageBase;
-            if ( pos < STAGE ) image[pos] = (uint8_t)byte; else R[addr] = (uint8_t)byte;   /* oversized piece */
-        };
-        const auto sixteen = [&] ( uint32_t quad ) {
-            if ( quad * 16 < kept ) {
-                const uint4 v = line[quad];
-                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    const auto put = [&] ( uint32_t addr, uint32_t byte ) {
+        const uint32_t pos = addr - imageBase;
+        if ( pos < STAGE ) image[pos] = (uint8_t)byte; else R[addr] = (uint8_t)byte;   /* oversized piece */
+    };
+    /* sixteen bytes (fewer at the segment's end) of a segment whose byte 0 goes to address a0 */
+    const auto sixteen = [&] ( const uint32_t* line, uint32_t quad, uint32_t a0, uint32_t bytes ) {
+        const uint4 v = reinterpret_cast<const uint4*>( line )[quad];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-                for ( uint32_t i = 0; i < 16; ++i ) {
-                    if ( quad * 16 + i < kept ) put( a - ( quad * 16 + i ), ( w[i >> 2] >> ( 8 * ( i & 3 ) ) ) & 0xFFu );
-                }
-            }
-        };
+        for ( uint32_t i = 0; i < 16; ++i ) {
+            if ( quad * 16 + i < bytes ) put( a0 - ( quad * 16 + i ), ( w[i >> 2] >> ( 8 * ( i & 3 ) ) ) & 0xFFu );
+        }
+    };
+    if ( t < count ) {
+        const uint32_t* const line = stashOfBlock + (size_t)seg * ( STASH / 4 );
         if constexpr ( STASH <= 128 ) {
 #pragma unroll
-            for ( uint32_t quad = 0; quad < STASH / 16; ++quad ) sixteen( quad );
-        } else {
-            for ( uint32_t quad = 0; quad * 16 < kept; ++quad ) sixteen( quad );
-        }
-        if ( len > STASH ) {
-            uint32_t p = seg_cont[base + seg];
-            a -= STASH;
-            for ( uint32_t i = STASH; i < len; ++i ) {
-                const uint32_t e = tab[p];
-                put( a, e & 0xFFu );
-                --a;
-                p = ( e >> 8 ) & LF_MASK;
+            for ( uint32_t quad = 0; quad < FIRST; ++quad ) {
+                if ( quad * 16 < kept ) sixteen( line, quad, addr0, kept );
             }
+        } else {
+            for ( uint32_t quad = 0; quad * 16 < kept; ++quad ) sixteen( line, quad, addr0, kept );
+        }
+    }
+    if constexpr ( STASH <= 128 ) {
+        for ( uint32_t i = t; i < laterTotal; i += EMIT_THREADS ) {
+            const uint32_t entry = later[i];
+            const uint32_t owner = entry >> 3, quad = entry & 7u;
+            sixteen( stashOfBlock + (size_t)segId[owner] * ( STASH / 4 ), quad, segAddr[owner], segLen[owner] );
+        }
+    }
+    if ( t < count && len > STASH ) {
+        /* the rare segment that is longer than its stash: the rest of its walk, again */
+        uint32_t p = seg_cont[base + seg];
+        uint32_t a = addr0 - STASH;
+        for ( uint32_t i = STASH; i < len; ++i ) {
+            const uint32_t e = tab[p];
+            put( a, e & 0xFFu );
+            --a;
+            p = ( e >> 8 ) & LF_MASK;
         }
     }
     __syncthreads();
@@ -475,6 +524,8 @@ k_emit( const BlockMeta* __restrict__ meta,
                 if ( pos >= beginPos && pos < endPos ) R[imageBase + pos] = image[pos];
             }
         }
+    }
+    __syncthreads();     /* the image and the lists are written again by the next piece */
     }
 }
 }  // namespace bz2gpu
