@@ -427,7 +427,7 @@ def main():
         traffic = None
         # PMC traffic of one step of this workload (tools/profile_round.sh traffic: separate FETCH_SIZE / WRITE_SIZE passes,
         # corrected as calibrated by tools/fetch_calib.sh), measured for the single-GPU case
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic_bench.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic_bench.json")
         if os.path.exists(tpath) and world == 1 and n_blocks == 2560 and args.workload == "silesia":
             traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         out = {

@@ -1078,10 +1078,11 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                                ? (uint32_t)std::atoi( wg )
                                : ( crowd ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
-    /* segments per claim: a big batch has millions of them (a claim of 1 024 costs a quarter of the barriers and counter
-     * updates: k_walk 22.1 -> 19.1 ms for the bench's batch with 64 workgroups per XCD), a lone block's 32 768 have to be
-     * spread over all workgroups */
-    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : ( n >= 64 ? 4 * WALK_CHUNK : WALK_CHUNK );
+    /* segments per claim.  (Claims of 1 024 instead of 256 in big batches make the walk itself faster -- 22.1 -> 19.3 ms alone
+     * with 64 workgroups per XCD, a quarter of the barriers and counter updates -- but spread an XCD's workgroups over four
+     * blocks' tables instead of one: FETCH_SIZE of k_walk 14.7 -> 77.6 GB per step, the gathers served by the Infinity Cache
+     * instead of the XCD's L2, and no gain for the step: profiles/r03_traffic_chunk1024.json) */
+    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
 
     const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: 1 = k_hscan<1>, 4 / 8 = k_hscan_spec<4 / 8>, whatever the batch size */
     const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;

@@ -155,33 +155,50 @@ rewrite_symbols( uint16_t* sym, uint32_t begin, uint32_t end, Step&& step )
     for ( ; i < end; ++i ) sym[i] = (uint16_t)step( (uint32_t)sym[i] );
 }
 
-/** Per-lane write combiner for a sequential byte stream: whole aligned dwords go out as one store (byte-granular
- * scattered stores cost a full write request each: 43 GB of fabric writes for 2.3 GB of L column, PMC WRITE_SIZE).  Only the
- * unaligned head and the tail of a lane's range, which share a dword with the neighbouring lane, are written bytewise.
+/** Per-lane write combiner for a sequential byte stream: whole aligned 16-byte units go out as one store.  The lanes of a
+ * wave write 3.5 KB apart, so every store is a partial line of its own: byte stores cost 43 GB of fabric writes for 2.3 GB of
+ * L column (PMC WRITE_SIZE), dword stores 10.3 GB, 16-byte units a third of that.  Only the unaligned head and the tail of a
+ * lane's range, which share a unit with the neighbouring lane, are written bytewise.
  * Runs are what this is tuned for: half the symbols of a text block are run digits, most runs are shorter than a dword, and
  * with a loop of single bytes per run the expansion was a third of k_mtf (3.7 of 11 ms per instance for the bench's batch,
- * profiles/r03_mtf_probe.txt): fill() completes the current dword and starts the last one with two masked ORs, its only loop is over
- * the whole dwords of a long run.
- * (Round 3 also tried whole 16-byte units per store -- three more registers for the dwords in front of the current one, a
- * select per completed dword: the L column's write traffic falls, but k_mtf took 14.5 instead of 8.9 ms (<144>) and 14.5
- * instead of 10.4 ms (<272>) for the bench's batch, the step 73 instead of 66 ms.  With the stores folded into a window of
- * 256 bytes per lane the kernel is as slow as with the real addresses: it is not the write traffic that bounds it.) */
+ * profiles/r03_mtf_probe.txt): fill() completes the current dword and starts the last one with two masked ORs, its only loops
+ * are over the whole dwords up to the next unit (at most three) and over the whole units of a long run.  (The first 16-byte
+ * form of round 3 aligned every run to a unit byte by byte: 14.5 instead of 8.9 ms.) */
 struct ByteSink
 {
     uint8_t* base;
     uint32_t lo;    /* first byte position of this lane's range */
     uint32_t o;     /* next byte position */
     uint32_t acc;   /* bytes of the dword that contains o, at their place */
+    uint32_t w0, w1, w2;   /* the complete dwords in front of it in the 16-byte unit that contains o */
 
+    /** bytes [from, to) of the unit that holds them all ({a, b, c, d} = its dwords) */
+    __device__ __forceinline__ void
+    bytes_out( uint32_t from, uint32_t to, uint32_t a, uint32_t b, uint32_t c, uint32_t d )
+    {
+        for ( uint32_t k = from; k < to; ++k ) {
+            const uint32_t q = ( k >> 2 ) & 3u;
+            const uint32_t word = q == 0 ? a : ( q == 1 ? b : ( q == 2 ? c : d ) );
+            base[k] = (uint8_t)( word >> ( 8 * ( k & 3u ) ) );
+        }
+    }
+
+    /** o is a multiple of 4: `acc` is the dword that ends there */
     __device__ __forceinline__ void
     word_done()
     {
-        /* o is a multiple of 4: `acc` is the dword that ends there */
-        if ( o - 4 >= lo ) {
-            *reinterpret_cast<uint32_t*>( base + o - 4 ) = acc;
+        const uint32_t q = ( ( o - 4 ) >> 2 ) & 3u;
+        if ( q == 3 ) {
+            if ( o >= 16 && o - 16 >= lo ) {
+                *reinterpret_cast<uint4*>( base + o - 16 ) = make_uint4( w0, w1, w2, acc );
+            } else {
+                bytes_out( lo, o, w0, w1, w2, acc );   /* the unit in which the range starts belongs to the previous lane as well */
+            }
+            w0 = w1 = w2 = 0;
         } else {
-            /* the dword in which the range starts belongs to the previous lane as well: bytes */
-            for ( uint32_t k = lo; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
+            w0 = q == 0 ? acc : w0;
+            w1 = q == 1 ? acc : w1;
+            w2 = q == 2 ? acc : w2;
         }
         acc = 0;
     }
@@ -207,23 +224,42 @@ struct ByteSink
             count -= take;
             if ( ( o & 3u ) == 0 ) word_done();
         }
-        /* (whatever is left starts a dword) */
-        for ( uint32_t k = count >> 2; k != 0; --k ) {
-            *reinterpret_cast<uint32_t*>( base + o ) = word;
+        /* (whatever is left starts a dword) whole dwords up to the next unit: at most three */
+        while ( count >= 4 && ( o & 15u ) != 0 ) {
+            acc = word;
             o += 4;
+            count -= 4;
+            word_done();
         }
-        const uint32_t rest = count & 3u;
-        acc |= word & ( ( 1u << ( 8 * rest ) ) - 1u );
-        o += rest;
+        /* whole units */
+        if ( count >= 16 ) {
+            const uint4 unit = make_uint4( word, word, word, word );
+            for ( uint32_t k = count >> 4; k != 0; --k ) {
+                *reinterpret_cast<uint4*>( base + o ) = unit;     /* (o >= lo: inside the range) */
+                o += 16;
+            }
+            count &= 15u;
+        }
+        /* whole dwords of the last unit, then the bytes that start its last dword */
+        while ( count >= 4 ) {
+            acc = word;
+            o += 4;
+            count -= 4;
+            word_done();
+        }
+        acc |= word & ( ( 1u << ( 8 * count ) ) - 1u );
+        o += count;
     }
 
     __device__ __forceinline__ void
     flush()
     {
-        /* the last, incomplete dword (shared with the next lane) */
-        const uint32_t first = ( o & ~3u ) > lo ? ( o & ~3u ) : lo;
-        for ( uint32_t k = first; k < o; ++k ) base[k] = (uint8_t)( acc >> ( 8 * ( k & 3u ) ) );
-        acc = 0;
+        /* the last, incomplete unit (shared with the next lane) */
+        const uint32_t unitStart = o & ~15u;
+        const uint32_t first = unitStart > lo ? unitStart : lo;
+        const uint32_t q = ( o >> 2 ) & 3u;     /* the dword `acc` stands for */
+        bytes_out( first, o, q == 0 ? acc : w0, q == 1 ? acc : w1, q == 2 ? acc : w2, acc );
+        acc = w0 = w1 = w2 = 0;
     }
 };
 
@@ -360,7 +396,7 @@ mtf_block( BlockMeta* __restrict__       meta,
         /* positions are 32-bit: a start beyond the buffer (only possible for damaged data, whose runs can add up to
          * anything) is clamped -- that lane then reports the overflow at its first symbol, an earlier lane wins anyway */
         const uint32_t startAt = prefix < MAX_N ? (uint32_t)prefix : MAX_N;
-        ByteSink sink{ L, startAt, startAt, 0 };
+        ByteSink sink{ L, startAt, startAt, 0, 0, 0, 0 };
         const uint8_t* const list = reinterpret_cast<const uint8_t*>( mine );
         uint32_t front = 0;       /* !REPLAY: position (in the start list) of the entry that is at the front now */
         uint32_t runPos = 0, hh = 0;

@@ -57,7 +57,7 @@ for name in ("bench", "config3"):
             calls[(k, row["Counter_Name"])] += 1
     steps = max(1, calls[("bz2gpu::k_crc", "FETCH_SIZE")])
     pipeline = [k for k in tot if "bz2gpu" in k and "k_find_magic" not in k]
-    factor = lambda k: 1 if k.endswith("k_walk") else 2
+    factor = lambda k: 1 if ("k_walk" in k and "plan" not in k) else 2
     fetch = sum(tot[k]["FETCH_SIZE"] * factor(k) for k in pipeline) * 1024 / steps
     fetch_hi = sum(tot[k]["FETCH_SIZE"] for k in pipeline) * 2048 / steps
     write = sum(tot[k]["WRITE_SIZE"] for k in pipeline) * 1024 / steps
