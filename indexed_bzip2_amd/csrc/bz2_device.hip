@@ -34,6 +34,7 @@ constexpr uint32_t MAX_CHUNKS = 3;          /* groups of cheap blocks; one more 
                                                default) would serialize two groups */
 constexpr int MAX_GROUPS = MAX_CHUNKS + 1;   /* + the expensive group */
 /* default register budgets of the kernels that would otherwise take 160 to 172 registers per lane (MI355X_BZ2_REGS) */
+constexpr uint32_t BWT_SPLIT_BLOCKS = 640;   /* batches up to this size build their tables with several workgroups per block */
 constexpr uint32_t REGS_SCAN = 4, REGS_SYM = 256 /* groups per k_hsym workgroup */, REGS_MTF = 4, REGS_LINK = 4;
 
 /** A host -> HBM copy of the input that runs in pieces on a thread and a stream of its own
@@ -151,6 +152,7 @@ struct mi355x_bz2_ctx
     uint32_t* dSlotOf{ nullptr };
     uint64_t* dTotals{ nullptr };     /* k_offsets: {total decoded bytes, does not fit} */
     uint32_t* dScanQueue{ nullptr };  /* [MAX_GROUPS]: block counters of k_hscan<1> launched with a capped grid */
+    uint32_t* dBwtCounts{ nullptr };  /* [min( cap, BWT_SPLIT_BLOCKS )][BWT_COUNTS_PER_BLOCK]: byte counts per chunk, small batches */
     uint64_t* hTotals{ nullptr };     /* pinned */
     BlockMeta* hMeta{ nullptr };       /* pinned */
     uint64_t* hOffsets{ nullptr };     /* pinned */
@@ -283,7 +285,7 @@ freeScratch( mi355x_bz2_ctx* c, bool now = true )
     c->dR = nullptr; c->dSegLen = nullptr; c->dSegSucc = nullptr; c->dSegCont = nullptr;
     c->dChain = nullptr; c->dStash = nullptr; c->dPlan = nullptr; c->dWalkBlk = nullptr; c->dWalkPre = nullptr;
     c->hOrder = nullptr; c->hSlotOf = nullptr; c->hMeta = nullptr; c->hOffsets = nullptr;
-    c->dSlotOf = nullptr; c->dTotals = nullptr; c->hTotals = nullptr; c->dScanQueue = nullptr;
+    c->dSlotOf = nullptr; c->dTotals = nullptr; c->hTotals = nullptr; c->dScanQueue = nullptr; c->dBwtCounts = nullptr;
     c->capacity = 0;
 }
 
@@ -330,6 +332,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t oSlotOf = reserve( deviceBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t oTotals = reserve( deviceBytes, 2 * sizeof( uint64_t ) );
     const size_t oScanQueue = reserve( deviceBytes, MAX_GROUPS * sizeof( uint32_t ) );
+    const size_t oBwtCounts = reserve( deviceBytes, (size_t)std::min( cap, BWT_SPLIT_BLOCKS ) * BWT_COUNTS_PER_BLOCK * sizeof( uint32_t ) );
     const size_t hOrderAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t hSlotOfAt = reserve( hostBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t hMetaAt = reserve( hostBytes, (size_t)cap * sizeof( BlockMeta ) );
@@ -369,6 +372,7 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dSlotOf = reinterpret_cast<uint32_t*>( d + oSlotOf );
     c->dTotals = reinterpret_cast<uint64_t*>( d + oTotals );
     c->dScanQueue = reinterpret_cast<uint32_t*>( d + oScanQueue );
+    c->dBwtCounts = reinterpret_cast<uint32_t*>( d + oBwtCounts );
     c->hOrder = reinterpret_cast<uint32_t*>( h + hOrderAt );
     c->hSlotOf = reinterpret_cast<uint32_t*>( h + hSlotOfAt );
     c->hMeta = reinterpret_cast<BlockMeta*>( h + hMetaAt );
@@ -1078,11 +1082,14 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                                ? (uint32_t)std::atoi( wg )
                                : ( crowd ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
-    /* segments per claim.  (Claims of 1 024 instead of 256 in big batches make the walk itself faster -- 22.1 -> 19.3 ms alone
-     * with 64 workgroups per XCD, a quarter of the barriers and counter updates -- but spread an XCD's workgroups over four
-     * blocks' tables instead of one: FETCH_SIZE of k_walk 14.7 -> 77.6 GB per step, the gathers served by the Infinity Cache
-     * instead of the XCD's L2, and no gain for the step: profiles/r03_traffic_chunk1024.json) */
-    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
+    /* Segments per claim.  A lane takes a new segment whenever it has finished one, so a claim has to hold several segments
+     * per lane for the lanes to stay busy (segment lengths are geometric: with one segment per lane 22 % of the lanes of a
+     * gather instruction are alive, PMC) -- but the segments an XCD has claimed should not span more than a block or two,
+     * or its workgroups work on more tables than its L2 holds (claims of 1 024 with 128 workgroups per XCD: FETCH_SIZE of
+     * k_walk 14.8 -> 77.6 GB per step).  Workgroups x claim = 32 768 = one block's segments; measured on one box, ms per
+     * step (k_walk alone): 128 x 256: 65.1 (17.3), 64 x 256: 63.3 (22.1), 64 x 512: 61.6 (18.7), 32 x 1 024: 60.9 / 62.0 (22.2),
+     * 24 x 1 536: 61.6, 16 x 2 048: 65.4.  In a crowd: 32 workgroups per XCD (an eighth of the wave slots) with claims of 1 024. */
+    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : ( crowd && n >= 256 ? 4 * WALK_CHUNK : WALK_CHUNK );
 
     const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: 1 = k_hscan<1>, 4 / 8 = k_hscan_spec<4 / 8>, whatever the batch size */
     const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;
@@ -1110,6 +1117,8 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
     bool longSegments = false;   /* measured slower for the bench's batch (k_link2 4.7 -> 1.8 ms, but k_walk 21 -> 32, k_emit 5.3 -> 10.8) */
     if ( const char* sg2 = std::getenv( "MI355X_BZ2_SEGMENTS" ) ) longSegments = sg2[0] == 'l';
     const uint32_t segTarget = longSegments ? KMAX / 4 : KMAX;
+    const char* bsp = std::getenv( "MI355X_BZ2_BWT_SPLIT" );   /* tuning knob: workgroups per block of the table build (1, 2, 4, 8) */
+    const uint32_t bwtSplit = bsp != nullptr ? std::min<uint32_t>( (uint32_t)std::atoi( bsp ), BWT_SPLIT_MAX ) : 0u;
     const char* smx = std::getenv( "MI355X_BZ2_SCAN_MIXED" );   /* 0: off; 4 / 8: that many waves per expensive block; default: by count */
     const uint32_t scanMixed = smx != nullptr ? (uint32_t)std::atoi( smx ) : 1u;
     const char* wsr = std::getenv( "MI355X_BZ2_WALK_SERIAL" );
@@ -1231,7 +1240,19 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             MTF256( MTF_LANE_STRIDE, q, 1 );
         }
 #undef MTF256
-        TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
+        /* table build: one workgroup per block when the batch fills the GPU with that (1 024 threads each: 512 at a time);
+         * fewer blocks are spread over 2, 4 or 8 workgroups each (a lone block: 1.0 -> 0.3 ms) */
+        const uint32_t bwtSlices = bwtSplit != 0 ? bwtSplit : ( n > BWT_SPLIT_BLOCKS ? 1u : ( n > 256 ? 2u : ( n > 128 ? 4u : BWT_SPLIT_MAX ) ) );
+        if ( bwtSlices > 1 && n <= BWT_SPLIT_BLOCKS ) {
+            uint32_t* const counts = c->dBwtCounts + (size_t)first * BWT_COUNTS_PER_BLOCK;
+            c->launched[g] |= 1u << 2;
+            HIP_TRY( c, hipEventRecord( c->ev[g][2 * 2], q ) );
+            hipLaunchKernelGGL( k_bwt_count, dim3( bwtSlices, m ), dim3( 1024 ), 0, q, meta, lcol, counts, bwtSlices );
+            hipLaunchKernelGGL( k_bwt_rank, dim3( bwtSlices, m ), dim3( 1024 ), 0, q, meta, lcol, tab, counts, bwtSlices );
+            HIP_TRY( c, hipEventRecord( c->ev[g][2 * 2 + 1], q ) );
+        } else {
+            TIMED_LAUNCH( c, g, q, 2, k_bwt_build, dim3( m ), dim3( 1024 ), 0, q, meta, lcol, tab );
+        }
         TIMED_LAUNCH( c, g, q, 10, k_walk_plan, dim3( 1 ), dim3( 256 ), 0, q, meta, m, plan, walkBlk, walkPre );
         if ( walkSerial ) {
             WalkChain& walks = walkChainOf( c->device );

@@ -327,6 +327,134 @@ k_bwt_build( const BlockMeta* __restrict__ meta,
     }
 }
 
+/* -------------------------------------------------------------------------------------------------------------
+ * The same table build for FEW blocks, a block spread over S workgroups (k_bwt_build runs ONE workgroup per block: a
+ * millisecond for a lone block, sixteen waves over 900 000 bytes one row at a time).  k_bwt_count: workgroup (s, b) counts
+ * the bytes of slice s of block b, per wavefront chunk (16 S chunks per block), into `counts`.  k_bwt_rank: workgroup
+ * (s, b) turns the counts of all chunks in front of its own into the first rank of every byte value in each of its
+ * chunks, then ranks its slice exactly as k_bwt_build's second pass does.
+ * ------------------------------------------------------------------------------------------------------------- */
+constexpr uint32_t BWT_SPLIT_MAX = 8;                                   /* most slices per block */
+constexpr uint32_t BWT_COUNTS_PER_BLOCK = BWT_SPLIT_MAX * BWT_WAVES * 256;   /* u32 */
+
+__device__ __forceinline__ void
+bwt_chunk_range( uint32_t N, uint32_t slices, uint32_t slice, uint32_t wave, uint32_t& begin, uint32_t& end )
+{
+    uint32_t chunk = ( N + slices * BWT_WAVES - 1 ) / ( slices * BWT_WAVES );
+    chunk = ( chunk + 255u ) & ~255u;
+    const uint32_t index = slice * BWT_WAVES + wave;
+    begin = index * chunk < N ? index * chunk : N;
+    end = begin + chunk < N ? begin + chunk : N;
+}
+
+__global__ __launch_bounds__( 1024 ) void
+k_bwt_count( const BlockMeta* __restrict__ meta,
+             const uint8_t* __restrict__   l_buf,
+             uint32_t* __restrict__        counts,     /* [block][slices * BWT_WAVES][256] */
+             uint32_t                      slices )
+{
+    __shared__ uint32_t hist[BWT_WAVES][256];
+    const uint32_t b = blockIdx.y, slice = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t begin, end;
+    bwt_chunk_range( mt.n, slices, slice, wave, begin, end );
+    for ( uint32_t i = tid; i < BWT_WAVES * 256; i += 1024 ) ( &hist[0][0] )[i] = 0;
+    __syncthreads();
+    for ( uint32_t base = begin; base < end; base += 256 ) {
+        const uint32_t i = base + 4 * lane;
+        if ( i < end ) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>( L + i );
+            const uint32_t nb = end - i < 4 ? end - i : 4;
+            for ( uint32_t k = 0; k < nb; ++k ) atomicAdd( &hist[wave][( v >> ( 8 * k ) ) & 0xFF], 1u );
+        }
+    }
+    __syncthreads();
+    uint32_t* const out = counts + (size_t)b * BWT_COUNTS_PER_BLOCK + (size_t)slice * BWT_WAVES * 256;
+    for ( uint32_t i = tid; i < BWT_WAVES * 256; i += 1024 ) out[i] = ( &hist[0][0] )[i];
+}
+
+__global__ __launch_bounds__( 1024 ) void
+k_bwt_rank( const BlockMeta* __restrict__ meta,
+            const uint8_t* __restrict__   l_buf,
+            uint32_t* __restrict__        tab_buf,
+            const uint32_t* __restrict__  counts,
+            uint32_t                      slices )
+{
+    __shared__ uint32_t hist[BWT_WAVES][256];    /* first rank of every byte value in this workgroup's chunks */
+    __shared__ uint32_t tot[256];
+    const uint32_t b = blockIdx.y, slice = blockIdx.x;
+    const BlockMeta mt = meta[b];
+    if ( !mt.walk_ok ) return;
+    const uint32_t N = mt.n, origPtr = mt.orig_ptr, stride = mt.seg_stride;
+    const uint8_t* const L = l_buf + (size_t)b * L_STRIDE;
+    uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if ( tid < 256 ) {
+        /* byte value `tid`: its count in the chunks in front of this slice, in this slice's chunks, and in all */
+        const uint32_t* const of = counts + (size_t)b * BWT_COUNTS_PER_BLOCK + tid;
+        uint32_t run = 0;
+        for ( uint32_t c = 0; c < slices * BWT_WAVES; ++c ) {
+            const uint32_t t = of[(size_t)c * 256];
+            if ( c / BWT_WAVES == slice ) hist[c % BWT_WAVES][tid] = run;
+            run += t;
+        }
+        tot[tid] = run;
+    }
+    __syncthreads();
+    if ( tid < 64 ) {
+        /* exclusive scan of the 256 totals: 4 per lane + wave scan */
+        uint32_t v0 = tot[4 * tid], v1 = tot[4 * tid + 1], v2 = tot[4 * tid + 2], v3 = tot[4 * tid + 3];
+        const uint32_t s4 = v0 + v1 + v2 + v3;
+        uint32_t incl = s4;
+        for ( int d = 1; d < 64; d <<= 1 ) {
+            const uint32_t o = __shfl_up( incl, d );
+            if ( (int)tid >= d ) incl += o;
+        }
+        uint32_t excl = incl - s4;
+        tot[4 * tid] = excl; excl += v0;
+        tot[4 * tid + 1] = excl; excl += v1;
+        tot[4 * tid + 2] = excl; excl += v2;
+        tot[4 * tid + 3] = excl;
+    }
+    __syncthreads();
+    if ( tid < 256 ) {
+        const uint32_t c = tot[tid];
+        for ( int w = 0; w < BWT_WAVES; ++w ) hist[w][tid] += c;
+    }
+    __syncthreads();
+
+    uint32_t begin, end;
+    bwt_chunk_range( N, slices, slice, wave, begin, end );
+    uint32_t rem = ( begin + lane ) % stride;
+    const uint32_t remStep = 64u % stride;
+    for ( uint32_t base4 = begin; base4 < end; base4 += 256 ) {
+        uint32_t keys[4];
+#pragma unroll
+        for ( uint32_t u = 0; u < 4; ++u ) keys[u] = L[base4 + 64 * u + lane];
+#pragma unroll
+        for ( uint32_t u = 0; u < 4; ++u ) {
+            const uint32_t i = base4 + 64 * u + lane;
+            const bool valid = i < end;
+            const uint32_t key = valid ? keys[u] : 0u;
+            const uint64_t same = match_any( key, 8, valid );
+            const uint32_t rank = popc_below( same, lane );
+            uint32_t basePos = 0;
+            if ( valid ) basePos = hist[wave][key];
+            if ( valid ) {
+                const uint32_t lf = basePos + rank;
+                const bool mark = ( rem == 0 ) || ( i == origPtr );
+                tab[i] = ( lf << 8 ) | key | ( mark ? MARK : 0u );
+                if ( rank == 0 ) hist[wave][key] = basePos + (uint32_t)__popcll( same );
+            }
+            rem += remStep;
+            if ( rem >= stride ) rem -= stride;
+        }
+    }
+}
+
 /** Blocks whose LF permutation does not have origPtr on an N-cycle (cycle length c < N; see k_link2): the reference's
  * forward walk over T = LF^-1 (bzip2.hpp:872-879) goes round that cycle for N steps, out[j] = X[j mod c].  The backward
  * walk here produced Y[k] = X[c-1-k] at R[N-1-k], k < c.  In terms of k that is R[N-1-k] = Y[(k - r) mod c] with

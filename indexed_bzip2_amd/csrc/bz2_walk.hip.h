@@ -27,7 +27,7 @@ namespace bz2gpu
 constexpr uint32_t WALK_THREADS = 256;
 constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
 constexpr uint32_t WALK_WGS_PER_XCD = 128;    /* one or two contexts */
-constexpr uint32_t WALK_WGS_CROWD = 64;       /* three or more contexts alive: see bz2_device.hip */
+constexpr uint32_t WALK_WGS_CROWD = 32;       /* three or more contexts alive, with claims of 4 x WALK_CHUNK: see bz2_device.hip */
 constexpr uint32_t WALK_QUEUES = 8;
 constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps when a block is cut into KMAX segments of
                                                 27 bytes on average (two 64-B lines per segment: 1 % of the bytes lie beyond,

@@ -491,14 +491,21 @@ def bench_slice(native):
     return _slice["v"]
 
 
-@pytest.mark.parametrize("variant", ["scan-1", "spec-4", "spec-8", "mtf-256", "segments-long", "regs-2", "regs-5", "sym-128", "sym-512"])
+@pytest.mark.parametrize("variant", ["scan-1", "spec-4", "spec-8", "mtf-256", "segments-long", "regs-2", "regs-5", "sym-128", "sym-512",
+                                     "bwt-1", "bwt-2", "bwt-4"])
 def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
     """Every kernel variant that a batch size or a tuning knob can select -- k_hscan<1> (one wavefront per block) with each of
     its register budgets, k_hscan_spec with 4 or 8 wavefronts per block, k_hsym with 128 / 256 / 512 groups per workgroup, the
     256-lane k_mtf instances with each register budget, long walk segments -- against the oracle, whatever the batch size would
     select by itself: valid data of all kinds, streams no libbz2 writes, one invalid stream per reference throw site, and
     seeded damage (every field of every record)."""
-    if variant == "mtf-256":
+    if variant.startswith("bwt-"):
+        # workgroups per block in the table build: 1 = k_bwt_build (what big batches use), 2 / 4 = k_bwt_count + k_bwt_rank with
+        # that many slices (small batches use 8 by themselves)
+        monkeypatch.setenv("MI355X_BZ2_BWT_SPLIT", variant.split("-")[1])
+        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1")
+        monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
+    elif variant == "mtf-256":
         # the 256-lane k_mtf instances, which batches of more than 256 blocks use (small batches take the 512-lane ones)
         monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     elif variant == "segments-long":
