@@ -1164,8 +1164,11 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             /* In a big batch the launch of one wave per block lasts as long as its largest block's chain (34 ms for an
              * incompressible block, against 14.6 ms of average wave life): the expensive minority gets its own waves per
              * group (MI355X_BZ2_SCAN_MIXED=0: one wave per block for them too) */
+            /* (in a crowd -- batches side by side, the scan of one under the other kernels of the rest -- one wave per block
+             * from 800 blocks on: a share of 1 270 blocks 37.5 -> 33.4 ms per step, of 960 blocks 28.1 -> 26.7, of 630 blocks
+             * 20.2 -> 20.7, profiles/r03_ab_share.txt) */
             uint32_t scanWaves = forcedScanWaves != 0 ? forcedScanWaves
-                                                      : ( n <= ( crowd ? 128u : 384u ) ? 8u : ( n <= 1280 ? 4u : 1u ) );
+                                                      : ( n <= ( crowd ? 128u : 384u ) ? 8u : ( n <= ( crowd ? 800u : 1280u ) ? 4u : 1u ) );
             if ( forcedScanWaves == 0 && scanWaves == 1 && g == expensiveGroup && scanMixed != 0 ) {
                 scanWaves = scanMixed >= 4 ? scanMixed : ( m <= 128 ? 8u : 4u );
             }
