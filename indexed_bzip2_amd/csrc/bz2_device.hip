@@ -33,9 +33,10 @@ using namespace bz2gpu;
 constexpr uint32_t MAX_CHUNKS = 3;          /* groups of cheap blocks; one more stream than hardware queues (4 by
                                                default) would serialize two groups */
 constexpr int MAX_GROUPS = MAX_CHUNKS + 1;   /* + the expensive group */
-/* default register budgets of the kernels that would otherwise take 160 to 172 registers per lane (MI355X_BZ2_REGS) */
+/* register budgets (wavefronts per SIMD that a kernel's registers leave room for, see k_hscan) and groups per chunk of k_hsym:
+ * the other values that round 3 built (2 / 5, 2 / 3, 128 / 512) made no difference for a step (profiles/r03_ab_registers.txt) */
 constexpr uint32_t BWT_SPLIT_BLOCKS = 640;   /* batches up to this size build their tables with several workgroups per block */
-constexpr uint32_t REGS_SCAN = 4, REGS_SYM = 256 /* groups per k_hsym workgroup */, REGS_MTF = 4, REGS_LINK = 4;
+constexpr uint32_t REGS_SCAN = 4, SYM_GROUPS = 256, REGS_MTF = 4;
 
 /** A host -> HBM copy of the input that runs in pieces on a thread and a stream of its own
  * (mi355x_bz2_set_input_host_streamed): a batch only waits for the piece in which its last block ends.  Shared by the
@@ -457,15 +458,11 @@ allowLargeLds()
     const auto allow = [&ok] ( const void* kernel, size_t bytes ) {
         ok = ok && hipFuncSetAttribute( kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes ) == hipSuccess;
     };
-    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, 2> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
-    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, 3> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
-    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, 4> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
+    allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, MTF_THREADS, REGS_MTF> ), sizeof( MtfShared<MTF_LANE_STRIDE, MTF_THREADS> ) );
     allow( reinterpret_cast<const void*>( &k_mtf<MTF_LANE_STRIDE, 512> ), sizeof( MtfShared<MTF_LANE_STRIDE, 512> ) );
     allow( reinterpret_cast<const void*>( &k_mtf<MTF_SMALL_STRIDE, 512> ), sizeof( MtfShared<MTF_SMALL_STRIDE, 512> ) );
     allow( reinterpret_cast<const void*>( &k_mtf<MTF_SMALL_STRIDE, 1024> ), sizeof( MtfShared<MTF_SMALL_STRIDE, 1024> ) );
-    allow( reinterpret_cast<const void*>( &k_hsym<512> ), sizeof( SymShared<512> ) );
-    allow( reinterpret_cast<const void*>( &k_link2<2> ), sizeof( LinkShared ) );
-    allow( reinterpret_cast<const void*>( &k_link2<4> ), sizeof( LinkShared ) );
+    allow( reinterpret_cast<const void*>( &k_link2 ), sizeof( LinkShared ) );
     return ok;
 }
 }  // namespace
@@ -1097,26 +1094,6 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
      * their blocks take (10 to 30 ms): the kernels of the other groups and contexts that need LDS wait for them */
     const char* sg = std::getenv( "MI355X_BZ2_SCAN_GRID" );
     const uint32_t scanGrid = sg != nullptr ? (uint32_t)std::atoi( sg ) : 0u;
-    /* register budgets (wavefronts per SIMD that a kernel's registers leave room for, see k_hscan):
-     * MI355X_BZ2_REGS="scan=4,sym=4,mtf=4,link=4"; 2 = what the compiler takes when it is only told the kernel's own LDS */
-    struct { uint32_t scan, sym, mtf, link; } regs = { REGS_SCAN, REGS_SYM, REGS_MTF, REGS_LINK };
-    if ( const char* text = std::getenv( "MI355X_BZ2_REGS" ) ) {
-        const auto value = [text] ( const char* key, uint32_t otherwise ) {
-            const char* at = std::strstr( text, key );
-            return at != nullptr && at[std::strlen( key )] == '=' ? (uint32_t)std::atoi( at + std::strlen( key ) + 1 ) : otherwise;
-        };
-        regs.scan = value( "scan", regs.scan );
-        regs.sym = value( "sym", regs.sym );
-        regs.mtf = value( "mtf", regs.mtf );
-        regs.link = value( "link", regs.link );
-    }
-    /* Walk segments per block.  Many short ones (KMAX = 32 768 of 27 bytes) make a lone block's walk short; a batch that
-     * fills the GPU anyway is better off with a quarter of them, four times as long: per-segment work (queue, records,
-     * k_link2's chain of 32 768 successors per block, k_emit's records) shrinks by four, the stash (512 instead of 128 bytes
-     * per segment) holds 99 % of the bytes either way.  MI355X_BZ2_SEGMENTS=long|short forces one. */
-    bool longSegments = false;   /* measured slower for the bench's batch (k_link2 4.7 -> 1.8 ms, but k_walk 21 -> 32, k_emit 5.3 -> 10.8) */
-    if ( const char* sg2 = std::getenv( "MI355X_BZ2_SEGMENTS" ) ) longSegments = sg2[0] == 'l';
-    const uint32_t segTarget = longSegments ? KMAX / 4 : KMAX;
     const char* bsp = std::getenv( "MI355X_BZ2_BWT_SPLIT" );   /* tuning knob: workgroups per block of the table build (1, 2, 4, 8) */
     const uint32_t bwtSplit = bsp != nullptr ? std::min<uint32_t>( (uint32_t)std::atoi( bsp ), BWT_SPLIT_MAX ) : 0u;
     const char* smx = std::getenv( "MI355X_BZ2_SCAN_MIXED" );   /* 0: off; 4 / 8: that many waves per expensive block; default: by count */
@@ -1189,27 +1166,17 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                 }
 #define SCAN1( W ) TIMED_LAUNCH( c, g, q, 12, ( k_hscan<1, W> ), dim3( grid ), dim3( 64 ), sizeof( ScanShared<1> ), q, inWords, inSize, \
                                  c->dOffsets + first, meta, hmeta, smeta, sel, stb, htab, gpos, m, order, scanTune, scanQueue )
-                if ( regs.scan >= 5 ) { SCAN1( 5 ); } else if ( regs.scan == 4 ) { SCAN1( 4 ); } else { SCAN1( 2 ); }
+                SCAN1( REGS_SCAN );
 #undef SCAN1
             }
 #define HSYM( T ) TIMED_LAUNCH( c, g, q, 13, k_hsym<T>, dim3( ( MAX_SCAN_GROUPS + ( T ) * SYM_CHUNKS - 1 ) / ( ( T ) * SYM_CHUNKS ), m ), dim3( T ), \
                                 sizeof( SymShared<T> ), q, inWords, meta, hmeta, smeta, sel, htab, gpos, sym )
-            if ( regs.sym >= 512 ) { HSYM( 512 ); } else if ( regs.sym >= 256 ) { HSYM( 256 ); } else { HSYM( 128 ); }
+            HSYM( SYM_GROUPS );
 #undef HSYM
         }
 #define MTF256( STRIDE, STREAM, INDEX ) \
-        do { \
-            if ( regs.mtf >= 4 ) { \
-                TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, 4> ), dim3( m ), dim3( MTF_THREADS ), \
-                              sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order, segTarget ); \
-            } else if ( regs.mtf == 3 ) { \
-                TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, 3> ), dim3( m ), dim3( MTF_THREADS ), \
-                              sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order, segTarget ); \
-            } else { \
-                TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, 2> ), dim3( m ), dim3( MTF_THREADS ), \
-                              sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order, segTarget ); \
-            } \
-        } while ( 0 )
+        TIMED_LAUNCH( c, g, STREAM, INDEX, ( k_mtf<STRIDE, MTF_THREADS, REGS_MTF> ), dim3( m ), dim3( MTF_THREADS ), \
+                      sizeof( MtfShared<STRIDE, MTF_THREADS> ), STREAM, meta, hmeta, sym, stb, lcol, m, order )
         /* Every block belongs to one of the two k_mtf instances (by its symbol count), the other returns at once.  In a
          * small batch each lasts as long as its slowest block (4 and 7 ms): side by side instead of one behind the other. */
         if ( n <= 1280 ) {
@@ -1226,12 +1193,12 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                 /* few blocks: 512 lanes per block, each with half the symbols */
                 if ( n <= 64 ) {
                     /* (the 128-entry lists of 1 024 lanes still fit the LDS of a CU: 152 KB) */
-                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 1024> ), dim3( m ), dim3( 1024 ), sizeof( MtfShared<MTF_SMALL_STRIDE, 1024> ), side, meta, hmeta, sym, stb, lcol, m, order, segTarget );
+                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 1024> ), dim3( m ), dim3( 1024 ), sizeof( MtfShared<MTF_SMALL_STRIDE, 1024> ), side, meta, hmeta, sym, stb, lcol, m, order );
                 } else {
-                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), sizeof( MtfShared<MTF_SMALL_STRIDE, 512> ), side, meta, hmeta, sym, stb, lcol, m, order, segTarget );
+                    TIMED_LAUNCH( c, g, side, 11, ( k_mtf<MTF_SMALL_STRIDE, 512> ), dim3( m ), dim3( 512 ), sizeof( MtfShared<MTF_SMALL_STRIDE, 512> ), side, meta, hmeta, sym, stb, lcol, m, order );
                 }
                 HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
-                TIMED_LAUNCH( c, g, q, 1, ( k_mtf<MTF_LANE_STRIDE, 512> ), dim3( m ), dim3( 512 ), sizeof( MtfShared<MTF_LANE_STRIDE, 512> ), q, meta, hmeta, sym, stb, lcol, m, order, segTarget );
+                TIMED_LAUNCH( c, g, q, 1, ( k_mtf<MTF_LANE_STRIDE, 512> ), dim3( m ), dim3( 512 ), sizeof( MtfShared<MTF_LANE_STRIDE, 512> ), q, meta, hmeta, sym, stb, lcol, m, order );
             } else {
                 MTF256( MTF_SMALL_STRIDE, side, 11 );
                 HIP_TRY( c, hipEventRecord( c->evJoin[g], side ) );
@@ -1261,38 +1228,19 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
             WalkChain& walks = walkChainOf( c->device );
             const std::scoped_lock chain( walks.mutex );
             if ( walks.last != nullptr ) HIP_TRY( c, hipStreamWaitEvent( q, walks.last, 0 ) );
-            if ( longSegments ) {
-                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES_LONG>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
-            } else {
-                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
-            }
+            TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
+                          meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
             hipEvent_t& slot = walks.events[walks.next++ % 64];
             if ( slot == nullptr ) HIP_TRY( c, hipEventCreateWithFlags( &slot, hipEventDisableTiming ) );
             HIP_TRY( c, hipEventRecord( slot, q ) );
             walks.last = slot;
         } else {
-            if ( longSegments ) {
-                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES_LONG>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
-            } else {
-                TIMED_LAUNCH( c, g, q, 3, k_walk<STASH_BYTES>, walkGrid, dim3( WALK_THREADS ), 0, q,
-                              meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
-            }
+            TIMED_LAUNCH( c, g, q, 3, k_walk, walkGrid, dim3( WALK_THREADS ), 0, q,
+                          meta, tab, plan, walkBlk, walkPre, segLen, segSucc, walkChunk, stash, segCont );
         }
-        if ( regs.link >= 4 ) {
-            TIMED_LAUNCH( c, g, q, 4, k_link2<4>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
-        } else {
-            TIMED_LAUNCH( c, g, q, 4, k_link2<2>, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
-        }
-        if ( longSegments ) {
-            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES_LONG>, dim3( ( KMAX / 4 + 2 + EMIT_THREADS * EMIT_TILES - 1 ) / ( EMIT_THREADS * EMIT_TILES ), m ), dim3( EMIT_THREADS ), 0, q,
-                          meta, tab, chain, stash, segCont, rbuf );
-        } else {
-            TIMED_LAUNCH( c, g, q, 5, k_emit<STASH_BYTES>, dim3( ( SEG_STRIDE + EMIT_THREADS * EMIT_TILES - 1 ) / ( EMIT_THREADS * EMIT_TILES ), m ), dim3( EMIT_THREADS ), 0, q,
-                          meta, tab, chain, stash, segCont, rbuf );
-        }
+        TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
+        TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS * EMIT_TILES - 1 ) / ( EMIT_THREADS * EMIT_TILES ), m ), dim3( EMIT_THREADS ), 0, q,
+                      meta, tab, chain, stash, segCont, rbuf );
         TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, lcol );
         TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );
         if ( g >= 1 ) {

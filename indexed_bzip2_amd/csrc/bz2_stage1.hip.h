@@ -292,7 +292,6 @@ mtf_block( BlockMeta* __restrict__       meta,
            uint8_t* __restrict__         l_buf,
            uint32_t                      n_blocks,
            const uint32_t* __restrict__  order,
-           uint32_t                      seg_target,
            uint8_t* __restrict__         listBytes,
            uint4* __restrict__           permRows,
            uint8_t* __restrict__         cur,
@@ -444,8 +443,8 @@ mtf_block( BlockMeta* __restrict__       meta,
         if ( status == ST_OK && origPtr >= N ) status = ST_ORIGPTR_DATA;
         meta[b].n = status == ST_OK || status == ST_ORIGPTR_DATA ? (uint32_t)total : 0u;
         meta[b].status = status;
-        /* walk segments: about seg_target of them (<= KMAX), a table entry in every `stride` a segment start */
-        uint32_t stride = ( N + seg_target - 1 ) / seg_target;
+        /* walk segments: up to KMAX of them, a table entry in every `stride` a segment start */
+        uint32_t stride = ( N + KMAX - 1 ) / KMAX;
         if ( stride < MIN_SEG_STRIDE ) stride = MIN_SEG_STRIDE;
         const uint32_t k0 = ( N + stride - 1 ) / stride;
         meta[b].seg_stride = stride;
@@ -463,12 +462,11 @@ k_mtf( BlockMeta* __restrict__       meta,
        const uint8_t* __restrict__   stb_buf,
        uint8_t* __restrict__         l_buf,
        uint32_t                      n_blocks,
-       const uint32_t* __restrict__  order,
-       uint32_t                      seg_target )   /* walk segments per block to aim for, 1 .. KMAX */
+       const uint32_t* __restrict__  order )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t ldsAtLaunch[];     /* sizeof( MtfShared<LANE_STRIDE, THREADS> ) */
     auto& shared = *reinterpret_cast<MtfShared<LANE_STRIDE, THREADS>*>( ldsAtLaunch );
-    mtf_block<LANE_STRIDE, THREADS>( meta, hmeta, sym_buf, stb_buf, l_buf, n_blocks, order, seg_target, shared.listBytes, shared.permRows,
+    mtf_block<LANE_STRIDE, THREADS>( meta, hmeta, sym_buf, stb_buf, l_buf, n_blocks, order, shared.listBytes, shared.permRows,
                                      shared.cur, shared.starts, shared.waveTotals, &shared.firstError );
 }
 }  // namespace bz2gpu

@@ -29,11 +29,10 @@ constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
 constexpr uint32_t WALK_WGS_PER_XCD = 128;    /* one or two contexts */
 constexpr uint32_t WALK_WGS_CROWD = 32;       /* three or more contexts alive, with claims of 4 x WALK_CHUNK: see bz2_device.hip */
 constexpr uint32_t WALK_QUEUES = 8;
-constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps when a block is cut into KMAX segments of
-                                                27 bytes on average (two 64-B lines per segment: 1 % of the bytes lie beyond,
-                                                10 % with one line); also what the stash buffer holds per segment slot */
-constexpr uint32_t STASH_BYTES_LONG = 512;   /* the same for batches whose blocks are cut into KMAX / 4 segments (108 bytes on
-                                                average, 0.9 % of the bytes beyond): same buffer, a quarter of the slots */
+constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps (two 64-B lines per segment: 1 % of the
+                                                bytes lie beyond, 10 % with one line).  Round 3 measured a quarter of the
+                                                segments with 512 stashed bytes each: k_link2 4.7 -> 1.8 ms, but k_walk 21 -> 32
+                                                and k_emit 5.3 -> 10.8 ms for the bench's batch; gone again */
 constexpr uint32_t EMIT_THREADS = 256;       /* segments (consecutive along the cycle) per k_emit workgroup */
 constexpr uint32_t EMIT_TILES = 4;           /* such pieces per workgroup, one after the other */
 constexpr uint32_t EMIT_STAGE = 16384;       /* LDS bytes that collect their output before it is written in whole lines */
@@ -237,9 +236,8 @@ link_block( BlockMeta*                   meta,
     }
 }
 
-/* W: wavefronts per SIMD the registers leave room for, LDS declared at launch -- see k_hscan (bz2_hscan.hip.h). */
-template<uint32_t W = 2>
-__global__ __launch_bounds__( LINK_THREADS ) __attribute__( ( amdgpu_waves_per_eu( W, 8 ) ) ) void
+/* LDS declared at launch -- see k_hscan (bz2_hscan.hip.h): the kernel needs 38 registers and was given 169. */
+__global__ __launch_bounds__( LINK_THREADS ) void
 k_link2( BlockMeta*                   meta,
          const uint32_t* __restrict__ seg_len,
          const uint32_t* __restrict__ seg_succ,
@@ -258,7 +256,6 @@ k_link2( BlockMeta*                   meta,
  * steps; the walk is bound by the latency of its dependent gathers, i.e. by how many of them are in flight.)  Within a claim
  * of `chunk` segments the runs that belong to one block are handled one after the other, so that everything a lane needs to
  * start a segment is uniform: its number, the stride, and one table look-up. */
-template<uint32_t STASH = STASH_BYTES>
 __global__ __launch_bounds__( WALK_THREADS ) void
 k_walk( const BlockMeta* __restrict__ meta,
          const uint32_t* __restrict__  tab_buf,
@@ -268,8 +265,8 @@ k_walk( const BlockMeta* __restrict__ meta,
          uint32_t*                     seg_len,
          uint32_t*                     seg_succ,
          uint32_t                      chunk,
-         uint32_t*                     stash,      /* [block][SEG_STRIDE * STASH_BYTES / 4]: STASH bytes per segment */
-         uint32_t*                     seg_cont )  /* table index of byte STASH of a longer segment */
+         uint32_t*                     stash,      /* [block][SEG_STRIDE * STASH_BYTES / 4]: STASH_BYTES bytes per segment */
+         uint32_t*                     seg_cont )  /* table index of byte STASH_BYTES of a longer segment */
 {
     __shared__ uint32_t sBase, sNext, sK0;
     const uint32_t tid = threadIdx.x;
@@ -333,7 +330,7 @@ k_walk( const BlockMeta* __restrict__ meta,
                     if ( !idle ) {
                         uint32_t w[4] = { 0, 0, 0, 0 };
                         bool done = false;
-                        if ( piece == STASH / 16 ) __builtin_nontemporal_store( p, seg_cont + segBase + j );   /* table index of byte STASH */
+                        if ( piece == STASH_BYTES / 16 ) __builtin_nontemporal_store( p, seg_cont + segBase + j );   /* table index of byte STASH_BYTES */
                         /* four steps per look at `done`: a lane whose segment ends inside the four goes on in place (it
                          * re-reads its last entry, adds nothing) instead of costing every step a change of the execution mask */
 #pragma unroll
@@ -350,10 +347,10 @@ k_walk( const BlockMeta* __restrict__ meta,
                                 }
                             }
                         }
-                        if ( piece < STASH / 16 ) {
-                            /* the segment's first STASH bytes, walk order, 16 bytes per store: k_emit then needs no second
+                        if ( piece < STASH_BYTES / 16 ) {
+                            /* the segment's first STASH_BYTES bytes, walk order, 16 bytes per store: k_emit then needs no second
                              * gather pass for them.  Written once, read much later: kept out of the way of the table lines */
-                            uint32_t* const out = stashOfBlock + (size_t)j * ( STASH / 4 ) + 4 * piece;
+                            uint32_t* const out = stashOfBlock + (size_t)j * ( STASH_BYTES / 4 ) + 4 * piece;
                             __builtin_nontemporal_store( w[0], out );
                             __builtin_nontemporal_store( w[1], out + 1 );
                             __builtin_nontemporal_store( w[2], out + 2 );
@@ -392,7 +389,6 @@ k_walk( const BlockMeta* __restrict__ meta,
  * 16-byte units.  The second full gather pass and its partial-line writes (120 GB read + 25 GB written per 2 GiB, PMC)
  * are gone.  Output addresses run backwards: byte i of the segment at offset `off` is R[N - 1 - off - i].
  */
-template<uint32_t STASH = STASH_BYTES, uint32_t STAGE = ( STASH <= 128 ? EMIT_STAGE : 3 * EMIT_STAGE )>
 __global__ __launch_bounds__( EMIT_THREADS ) void
 k_emit( const BlockMeta* __restrict__ meta,
         const uint32_t* __restrict__  tab_buf,
@@ -401,12 +397,13 @@ k_emit( const BlockMeta* __restrict__ meta,
         const uint32_t* __restrict__  seg_cont,   /* table index of byte STASH of a longer segment */
         uint8_t* __restrict__         r_buf )
 {
+    constexpr uint32_t STASH = STASH_BYTES, STAGE = EMIT_STAGE;
     constexpr uint32_t FIRST = 2;                                /* 16-byte pieces of a segment that its own lane takes */
     constexpr uint32_t MORE = STASH / 16 - FIRST;                /* further pieces a segment can have in the stash */
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t image[STAGE + 16];
     __shared__ uint32_t sLow, sTop;                              /* lowest / highest output address of the piece */
     __shared__ uint32_t segAddr[EMIT_THREADS], segLen[EMIT_THREADS], segId[EMIT_THREADS];
-    __shared__ uint16_t later[STASH <= 128 ? EMIT_THREADS * MORE : 1];   /* pieces behind the first two: lane << 3 | piece */
+    __shared__ uint16_t later[EMIT_THREADS * MORE];   /* pieces behind the first two: lane << 3 | piece */
     __shared__ uint32_t waveSum[EMIT_THREADS / 64];
     const uint32_t b = blockIdx.y;
     const BlockMeta mt = meta[b];
@@ -434,7 +431,7 @@ k_emit( const BlockMeta* __restrict__ meta,
     const uint32_t kept = t < count ? ( len < STASH ? len : STASH ) : 0u;
     const uint32_t addr0 = N - 1 - off;                   /* address of byte 0 */
     uint32_t laterTotal = 0;
-    if constexpr ( STASH <= 128 ) {
+    {
         /* Segment lengths are geometric (mean 27): a lane that copies ITS segment runs the longest segment's eight pieces with
          * one lane in five alive (3.5 of k_emit's 5.4 ms for the bench's batch were that skeleton).  So a lane copies the
          * first two pieces of its segment -- 70 % of the segments end there -- and the pieces behind them are listed and
@@ -482,16 +479,12 @@ k_emit( const BlockMeta* __restrict__ meta,
     };
     if ( t < count ) {
         const uint32_t* const line = stashOfBlock + (size_t)seg * ( STASH / 4 );
-        if constexpr ( STASH <= 128 ) {
 #pragma unroll
-            for ( uint32_t quad = 0; quad < FIRST; ++quad ) {
-                if ( quad * 16 < kept ) sixteen( line, quad, addr0, kept );
-            }
-        } else {
-            for ( uint32_t quad = 0; quad * 16 < kept; ++quad ) sixteen( line, quad, addr0, kept );
+        for ( uint32_t quad = 0; quad < FIRST; ++quad ) {
+            if ( quad * 16 < kept ) sixteen( line, quad, addr0, kept );
         }
     }
-    if constexpr ( STASH <= 128 ) {
+    {
         for ( uint32_t i = t; i < laterTotal; i += EMIT_THREADS ) {
             const uint32_t entry = later[i];
             const uint32_t owner = entry >> 3, quad = entry & 7u;

@@ -491,14 +491,12 @@ def bench_slice(native):
     return _slice["v"]
 
 
-@pytest.mark.parametrize("variant", ["scan-1", "spec-4", "spec-8", "mtf-256", "segments-long", "regs-2", "regs-5", "sym-128", "sym-512",
-                                     "bwt-1", "bwt-2", "bwt-4"])
+@pytest.mark.parametrize("variant", ["scan-1", "spec-4", "spec-8", "mtf-256", "bwt-1", "bwt-2", "bwt-4"])
 def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
-    """Every kernel variant that a batch size or a tuning knob can select -- k_hscan<1> (one wavefront per block) with each of
-    its register budgets, k_hscan_spec with 4 or 8 wavefronts per block, k_hsym with 128 / 256 / 512 groups per workgroup, the
-    256-lane k_mtf instances with each register budget, long walk segments -- against the oracle, whatever the batch size would
-    select by itself: valid data of all kinds, streams no libbz2 writes, one invalid stream per reference throw site, and
-    seeded damage (every field of every record)."""
+    """Every kernel variant that a batch size can select -- k_hscan<1> (one wavefront per block), k_hscan_spec with 4 or 8
+    wavefronts per block, the 256-lane k_mtf instances, the table build with 1, 2 or 4 workgroups per block (small batches
+    use 8 by themselves) -- against the oracle, whatever the batch size would select by itself: valid data of all kinds,
+    streams no libbz2 writes, one invalid stream per reference throw site, and seeded damage (every field of every record)."""
     if variant.startswith("bwt-"):
         # workgroups per block in the table build: 1 = k_bwt_build (what big batches use), 2 / 4 = k_bwt_count + k_bwt_rank with
         # that many slices (small batches use 8 by themselves)
@@ -507,18 +505,6 @@ def test_huffman_stage_variants(native, oracle, variant, monkeypatch):
         monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     elif variant == "mtf-256":
         # the 256-lane k_mtf instances, which batches of more than 256 blocks use (small batches take the 512-lane ones)
-        monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
-    elif variant == "segments-long":
-        # a quarter of the walk segments, 512 stashed bytes each (a measured alternative for big batches), with the kernels of
-        # big batches (one scan wave per block, 256-lane k_mtf)
-        monkeypatch.setenv("MI355X_BZ2_SEGMENTS", "long")
-        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1")
-        monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
-    elif variant.startswith("regs-") or variant.startswith("sym-"):
-        # the other register budgets of k_hscan<1> / k_mtf / k_link2 and the other workgroup sizes of k_hsym
-        monkeypatch.setenv("MI355X_BZ2_REGS", {"regs-2": "scan=2,mtf=2,link=2", "regs-5": "scan=5,mtf=3,link=4",
-                                               "sym-128": "sym=128", "sym-512": "sym=512"}[variant])
-        monkeypatch.setenv("MI355X_BZ2_SCAN_WAVES", "1")
         monkeypatch.setenv("MI355X_BZ2_MTF_NARROW", "1")
     else:
         # scan-1: k_hscan<1>; spec-N: N waves on N consecutive groups (k_hscan_spec<N>)
