@@ -313,7 +313,6 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     const size_t oOrder = reserve( deviceBytes, (size_t)cap * sizeof( uint32_t ) );
     const size_t oMeta = reserve( deviceBytes, (size_t)cap * sizeof( BlockMeta ) );
     const size_t oSel = reserve( deviceBytes, (size_t)cap * SEL_STRIDE + 256 );
-    const size_t oSym = reserve( deviceBytes, (size_t)cap * SYM_STRIDE * sizeof( uint16_t ) );
     const size_t oStb = reserve( deviceBytes, (size_t)cap * 256 );
     const size_t oHmeta = reserve( deviceBytes, (size_t)cap * sizeof( HuffMeta ) );
     const size_t oSmeta = reserve( deviceBytes, (size_t)cap * sizeof( ScanMeta ) );
@@ -353,7 +352,6 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dOrder = reinterpret_cast<uint32_t*>( d + oOrder );
     c->dMeta = reinterpret_cast<BlockMeta*>( d + oMeta );
     c->dSel = d + oSel;
-    c->dSym = reinterpret_cast<uint16_t*>( d + oSym );
     c->dStb = d + oStb;
     c->dHmeta = reinterpret_cast<HuffMeta*>( d + oHmeta );
     c->dSmeta = reinterpret_cast<ScanMeta*>( d + oSmeta );
@@ -367,6 +365,10 @@ ensureScratch( mi355x_bz2_ctx* c, uint32_t nBlocks )
     c->dSegCont = reinterpret_cast<uint32_t*>( d + oSegCont );
     c->dChain = reinterpret_cast<uint2*>( d + oChain );
     c->dStash = reinterpret_cast<uint32_t*>( d + oStash );
+    /* the Huffman symbols of a block (k_hsym -> k_mtf) live where the block's stash will be (k_walk -> k_emit): same slot
+     * size, never alive together, producers and consumers of a block slot on one stream in that order; 1.8 MB per block less */
+    static_assert( (size_t)SYM_STRIDE * sizeof( uint16_t ) == (size_t)SEG_STRIDE * STASH_BYTES );
+    c->dSym = reinterpret_cast<uint16_t*>( d + oStash );
     c->dPlan = reinterpret_cast<WalkPlan*>( d + oPlan );
     c->dWalkBlk = reinterpret_cast<uint32_t*>( d + oWalkBlk );
     c->dWalkPre = reinterpret_cast<uint32_t*>( d + oWalkPre );

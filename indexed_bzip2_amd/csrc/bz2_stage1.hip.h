@@ -16,7 +16,10 @@
 
 namespace bz2gpu
 {
-constexpr uint32_t SYM_STRIDE = 900224;       /* u16 symbols per block (n_sym <= N + 1 <= 900001 for valid blocks) */
+constexpr uint32_t SYM_STRIDE = SEG_STRIDE * 64;   /* u16 per block slot.  A block has at most 900 100 symbols (n_sym <= N + 1); the slot
+                                                    is as large as the block's slot of the walk's stash (SEG_STRIDE x 128 B), because
+                                                    the two share memory: the symbols are dead when k_mtf is through, the stash is
+                                                    written by k_walk behind it on the same stream (bz2_device.hip) */
 constexpr uint32_t SYM_CAP = 900096;
 constexpr uint32_t MTF_THREADS = 256;      /* lanes (= chunks) per block in k_mtf: one workgroup per block */
 constexpr uint32_t MTF_SMALL_STRIDE = 144;  /* lists of 128 entries for blocks with few symbols, see k_mtf */
