@@ -474,6 +474,12 @@ def main():
         if alone:
             out["roofline"]["kernel_ms_sum_alone"] = round(alone["ms_kernel_sum"], 3)
             out["roofline"]["dominant_kernel"] = max(alone["kernels"], key=alone["kernels"].get)
+        memory = [d.device_memory() for d in decs]
+        out["config"]["device_memory_GB"] = {
+            "contexts": len(decs),
+            "scratch": round(sum(m["scratch_bytes"] for m in memory) / 1e9, 2),
+            "output_buffers": round(sum(m["output_bytes"] for m in memory) / 1e9, 2),
+            "scratch_MB_per_block": round(memory[0]["scratch_bytes"] / max(1, n_blocks) / 1e6, 2)}
         if host_dt is not None:
             out["config"]["host_output_MBps"] = round(job_decoded * host_steps / host_dt / 1e6, 1)
             out["config"]["host_output_ms_per_step"] = round(host_dt / host_steps * 1e3, 3)

@@ -206,8 +206,12 @@ int mi355x_bz2_last_timings( const mi355x_bz2_ctx* ctx, mi355x_bz2_timings* timi
 int mi355x_bz2_last_pipeline_ms( const mi355x_bz2_ctx* ctx, float* milliseconds );
 /* The hipStream_t the context launches on (as void*), so callers can order their own work after it. */
 void* mi355x_bz2_stream( const mi355x_bz2_ctx* ctx );
+/* Device memory the context holds right now: the per-block scratch (sized by the largest batch so far) and its output
+ * buffers (sized by the largest batch's decoded bytes; two once a background copy has been used).  Either pointer may
+ * be NULL.  No counterpart in the reference (its decoders keep ~5 bytes per decoded byte on the heap, bzip2.hpp:425-441). */
+int mi355x_bz2_device_memory( const mi355x_bz2_ctx* ctx, uint64_t* scratch_bytes, uint64_t* output_bytes );
 
-/* Debug/parity hook (needs MI355X_BZ2_FLAG_KEEP_STAGES): copy an intermediate stage of block `index` of the last
+/* Debug/parity hook (needs MI355X_BZ2_FLAG_KEEP_STAGES -- without it stages 0 and 2 share their memory and are refused): copy an intermediate stage of block `index` of the last
  * batch to host. stage 0 = L column (N bytes, bzip2.hpp:789 dbuf low bytes), 1 = packed LF table (4N bytes),
  * 2 = inverse-BWT output before RLE1 (N bytes). */
 int mi355x_bz2_debug_copy_stage( mi355x_bz2_ctx* ctx, uint32_t index, int stage, void* host_dst, uint64_t capacity );

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("mi355x_bz2_last_pipeline_ms", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     ("mi355x_bz2_kernel_name", ctypes.c_char_p, [ctypes.c_uint32]),
     ("mi355x_bz2_stream", _vp, [_vp]),
+    ("mi355x_bz2_device_memory", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("mi355x_bz2_debug_copy_stage", ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_int, _vp, ctypes.c_uint64]),
     ("mi355x_bz2_find_magic", ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _u64p,
                                                  ctypes.c_uint64, ctypes.c_uint32]),
@@ -325,6 +326,12 @@ class Decoder:
 
     def stream_ptr(self) -> int:
         return lib().mi355x_bz2_stream(self._h) or 0
+
+    def device_memory(self) -> dict:
+        """bytes of HBM this context holds: per-block scratch and output buffers"""
+        scratch, output = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(lib().mi355x_bz2_device_memory(self._h, ctypes.byref(scratch), ctypes.byref(output)))
+        return {"scratch_bytes": scratch.value, "output_bytes": output.value}
 
     def hold_output_until(self, hip_event: int, keepalive=None):
         """The next batch's output kernels wait for `hip_event` (e.g. torch.cuda.Event.cuda_event recorded behind a

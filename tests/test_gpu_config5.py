@@ -83,9 +83,10 @@ def test_random_pread_with_imported_index(native, silesia_file, exported_index, 
         # nothing was decoded to build an index, and random access does not decode the file front to back: a 64 KiB read
         # touches one or two blocks, and two neighbours in a row look like the start of a sequential read to the access
         # tracker (as to the reference's FetchNextAdaptive), which then decodes a few blocks ahead: measured 1.3 blocks
-        # per read at parallelization 1, 6.5 at 4
+        # per read at parallelization 1, 6.5 at 4, 13 to 17 at 0 (how far a look-ahead gets before the next seek depends on
+        # the timing)
         print(f"config 5, parallelization {parallelization}: {stats}")
-        assert stats["blocks_decoded"] <= READS * 16
+        assert stats["blocks_decoded"] <= READS * (4 if parallelization == 1 else 32)
         # the imported index is what the reader reports
         assert f.block_offsets() == exported_index
         # the last bytes and the end of the file

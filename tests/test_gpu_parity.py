@@ -167,6 +167,35 @@ def test_begin_end_halves_and_two_contexts(native, oracle):
         d.close()
 
 
+def test_device_memory_and_the_stage_buffers(native, oracle):
+    """mi355x_bz2_device_memory; a context made without KEEP_STAGES lets the inverse BWT's bytes take the place of the last
+    column (0.9 MB per block less) and refuses to show the two, one made with the flag keeps both."""
+    raw = datagen.text_like(1_200_000, 77)
+    enc = datagen.compress(raw, 9)
+    offs = native.find_magic(enc)
+    plain, keeping = native.Decoder(), native.Decoder(flags=native.Decoder.KEEP_STAGES)
+    try:
+        assert plain.device_memory() == {"scratch_bytes": 0, "output_bytes": 0}
+        for d in (plain, keeping):
+            d.set_input(enc)
+            results, total = d.decode_batch(offs)
+            assert total == len(raw) and d.copy_output(0, total) == raw
+        small, large = plain.device_memory(), keeping.device_memory()
+        assert 0 < small["scratch_bytes"] < large["scratch_bytes"]
+        assert small["output_bytes"] >= len(raw) and large["output_bytes"] >= len(raw)
+        # two blocks round up to eight slots: 900 000 bytes (+ padding) each
+        assert 8 * 900_000 <= large["scratch_bytes"] - small["scratch_bytes"] <= 8 * 1_000_000
+        lcol = oracle.decode_block(enc, offs[0], want_stages=True)[2]
+        assert keeping.debug_stage(0, 0) == lcol
+        for stage in (0, 2):
+            with pytest.raises(native.Bz2Error):
+                plain.debug_stage(0, stage)
+        assert len(plain.debug_stage(0, 1)) == 4 * len(lcol)       # the table is its own buffer either way
+    finally:
+        plain.close()
+        keeping.close()
+
+
 def test_two_contexts_over_one_resident_input(native, oracle):
     """mi355x_bz2_share_input: the second context decodes from the bytes the first one uploaded (what the reader does
     for its two contexts); halves of the block list on each, interleaved."""
