@@ -159,7 +159,7 @@ template<uint32_t K, uint32_t RW, bool NEAR_END, int PART = SCAN_ALL, uint32_t R
 __device__ __forceinline__ void
 scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p, uint32_t sizeBits,
             const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool firstOnly, uint32_t lane, uint32_t wave,
-            uint32_t endRows = 0, uint32_t endBase = 0, uint32_t levels = 5 )
+            uint32_t endRows = 0, uint32_t endBase = 0 )
 {
     constexpr uint32_t S = 64 * K * RW;
     constexpr uint32_t OUT = 2 * S, TERM = 2 * S + 2;
@@ -243,10 +243,8 @@ scan_build( ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_
     scan_sync<K>();
     SCAN_LEVEL( A, TO_B )   /* J2 -> b (kept) */
     SCAN_LEVEL( B, TO_C )   /* J4 */
-    SCAN_LEVEL( C, 0 )      /* J8 -> a */
-    if ( PART == SCAN_ALL && levels == 3 ) return;      /* the chase goes on from J8 (in a) and J2 (in b) */
+    SCAN_LEVEL( C, 0 )      /* J8 */
     SCAN_LEVEL( A, TO_C )   /* J16 -> c (kept) */
-    if ( PART == SCAN_ALL && levels == 4 ) return;      /* from J16 (in c) and J2 */
     if constexpr ( PART == SCAN_ENDS ) {
         /* 16 + 16 + 16 + 2 symbols from each of the first positions (own[] = J16 of them) -> a (J8 is not needed any more),
          * as bit positions from endBase bits in front of the span: what the chain of k_hscan_spec reads */
@@ -665,20 +663,20 @@ template<uint32_t K, int PART = SCAN_ALL, uint32_t RING = SCAN_RING_ENTRIES>
 __device__ __forceinline__ void
 scan_build_rows( uint32_t rw, bool nearEnd, ScanSlot& slot, const uint8_t* lenlut, const uint32_t* ring, uint32_t p,
                  uint32_t sizeBits, const uint32_t ( &lim )[10], uint32_t eobLo, uint32_t eobHi, bool one, uint32_t lane,
-                 uint32_t wave, uint32_t endRows = 0, uint32_t endBase = 0, uint32_t levels = 5 )
+                 uint32_t wave, uint32_t endRows = 0, uint32_t endBase = 0 )
 {
     constexpr uint32_t MAX = SCAN_ROWS / K;
 #define SCAN_CASE( n ) \
     if constexpr ( ( n ) <= MAX ) { \
-        if ( rw == ( n ) ) { scan_build<K, ( n ), false, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase, levels ); return; } \
+        if ( rw == ( n ) ) { scan_build<K, ( n ), false, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase ); return; } \
     }
     if ( nearEnd ) {
-        scan_build<K, MAX, true, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase, levels );
+        scan_build<K, MAX, true, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
         return;
     }
     SCAN_CASE( 1 ) SCAN_CASE( 2 ) SCAN_CASE( 3 ) SCAN_CASE( 4 ) SCAN_CASE( 5 ) SCAN_CASE( 6 ) SCAN_CASE( 8 ) SCAN_CASE( 10 )
     SCAN_CASE( 12 )
-    scan_build<K, MAX, false, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase, levels );
+    scan_build<K, MAX, false, PART, RING>( slot, lenlut, ring, p, sizeBits, lim, eobLo, eobHi, one, lane, wave, endRows, endBase );
 #undef SCAN_CASE
 }
 
@@ -819,36 +817,17 @@ k_hscan( const uint32_t* __restrict__ in_words,
                 }
                 lastS[which] = S;
             }
-            /* Rounds of doubling: a round costs two LDS instructions per row of the span, whatever the number of groups in it;
-             * what the rounds leave out, every group's chase makes up for with dependent look-ups (J32: 3 per group, J16: 4,
-             * J8: 7). */
-            uint32_t levels = 5;
-            if ( ( tune & 8u ) || ( ( tune & 4u ) && m <= 2 ) ) levels = 3;
-            if ( tune & 16u ) levels = 4;
-            scan_build_rows<K>( rw, nearEnd, slot, sh.lenlut[t], sh.ring, p, sizeBits, lim, eobLo, eobHi, m == 1 && levels == 5, lane, wave,
-                                0, 0, levels );
+            scan_build_rows<K>( rw, nearEnd, slot, sh.lenlut[t], sh.ring, p, sizeBits, lim, eobLo, eobHi, m == 1, lane, wave );
 
-            /* chase: 32 + 16 + 2 (or 3 x 16 + 2, or 6 x 8 + 2) symbols per group; x and the entries are byte offsets
-             * (2 x position) */
-            const uint8_t* const inA = slot.bytes();                      /* J32, or J8 after three rounds */
+            /* chase: 32 + 16 + 2 symbols per group; x and the entries are byte offsets (2 x position) */
+            const uint8_t* const J32 = slot.bytes();
             const uint8_t* const J16 = slot.bytes() + 2 * LEV_BYTES;
             const uint8_t* const J2 = slot.bytes() + LEV_BYTES;
             uint32_t x = 0, done = 0;
             bool stopAll = false;
             for ( uint32_t j = 0; j < m; ++j ) {
-                uint32_t r16;
-                if ( levels == 5 ) {
-                    const uint32_t q = *reinterpret_cast<const uint16_t*>( inA + x );
-                    r16 = *reinterpret_cast<const uint16_t*>( J16 + q );
-                } else if ( levels == 4 ) {
-                    r16 = *reinterpret_cast<const uint16_t*>( J16 + x );
-                    r16 = *reinterpret_cast<const uint16_t*>( J16 + r16 );
-                    r16 = *reinterpret_cast<const uint16_t*>( J16 + r16 );
-                } else {
-                    r16 = *reinterpret_cast<const uint16_t*>( inA + x );
-#pragma unroll
-                    for ( uint32_t k = 0; k < 5; ++k ) r16 = *reinterpret_cast<const uint16_t*>( inA + r16 );
-                }
+                const uint32_t q = *reinterpret_cast<const uint16_t*>( J32 + x );
+                const uint32_t r16 = *reinterpret_cast<const uint16_t*>( J16 + q );
                 const uint32_t u = sfl( *reinterpret_cast<const uint16_t*>( J2 + r16 ) );
                 if ( u == 2 * S ) {                   /* left the span: again from here, the first group with the full span */
                     forceFull = j == 0;
