@@ -94,7 +94,7 @@ def config2(out):
 
 def config3(out):
     common = ["--workload", "urandom", "--no-host-output"]
-    four = run_bench(common + ["--steps", "8", "--warmup", "4"])
+    four = run_bench(common + ["--steps", "12", "--warmup", "6"])
     one = run_bench(common + ["--steps", "4", "--warmup", "2", "--contexts", "1", "--resident"])
     path = os.path.join(CACHE, "urandom-214748364-x2147483648-l9-v3.bz2")
     out["config3_urandom"] = {
