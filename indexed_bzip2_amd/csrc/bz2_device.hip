@@ -1084,14 +1084,14 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
                                ? (uint32_t)std::atoi( wg )
                                : ( crowd ? WALK_WGS_CROWD : WALK_WGS_PER_XCD );
     const char* wc = std::getenv( "MI355X_BZ2_WALK_CHUNK" );
-    /* Segments per grab of a wave (k_walk).  What an XCD has in flight -- its lanes plus the waves' reserves -- should not
-     * span more than a block or two (32 768 segments each), or its waves work on more tables than its L2 holds (claims of
-     * 1 024 per workgroup with 128 workgroups per XCD: FETCH_SIZE of k_walk 14.8 -> 77.6 GB per step).  Measured on one
-     * box, workgroups per XCD x grab: ms per step of the bench (k_walk alone): 32 x 64: 60.8 (21.6), 32 x 128: 60.4 (21.5),
-     * 32 x 256: 60.7 (22.8), 64 x 64: 64.0 (17.4), 64 x 128: 64.7 (17.8), 64 x 256: 68.4 (22.7), 128 x 64: 75.9 (21.9);
-     * a grab of 32 is less than a wave asks for per round: 64 x 32: 66.4 (29.9).  In a crowd: 32 workgroups per XCD (an
-     * eighth of the wave slots); a batch by itself: 64. */
-    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : WALK_CHUNK;
+    /* Segments per claim.  A lane takes a new segment whenever it has finished one, so a claim has to hold several segments
+     * per lane for the lanes to stay busy (segment lengths are geometric: with one segment per lane 22 % of the lanes of a
+     * gather instruction are alive, PMC) -- but the segments an XCD has claimed should not span more than a block or two,
+     * or its workgroups work on more tables than its L2 holds (claims of 1 024 with 128 workgroups per XCD: FETCH_SIZE of
+     * k_walk 14.8 -> 77.6 GB per step).  Workgroups x claim = 32 768 = one block's segments; measured on one box, ms per
+     * step (k_walk alone): 128 x 256: 65.1 (17.3), 64 x 256: 63.3 (22.1), 64 x 512: 61.6 (18.7), 32 x 1 024: 60.9 / 62.0 (22.2),
+     * 24 x 1 536: 61.6, 16 x 2 048: 65.4.  In a crowd: 32 workgroups per XCD (an eighth of the wave slots) with claims of 1 024. */
+    const uint32_t walkChunk = wc != nullptr && std::atoi( wc ) > 0 ? (uint32_t)std::atoi( wc ) : ( crowd && n >= 256 ? 4 * WALK_CHUNK : WALK_CHUNK );
 
     const char* sw = std::getenv( "MI355X_BZ2_SCAN_WAVES" );   /* tuning knob: 1 = k_hscan<1>, 4 / 8 = k_hscan_spec<4 / 8>, whatever the batch size */
     const uint32_t forcedScanWaves = sw != nullptr && std::atoi( sw ) > 0 ? (uint32_t)std::atoi( sw ) : 0u;

@@ -25,9 +25,9 @@
 namespace bz2gpu
 {
 constexpr uint32_t WALK_THREADS = 256;
-constexpr uint32_t WALK_CHUNK = 64;          /* segments per grab of a wave: one per lane */
-constexpr uint32_t WALK_WGS_PER_XCD = 64;     /* one or two contexts */
-constexpr uint32_t WALK_WGS_CROWD = 32;       /* three or more contexts alive: see bz2_device.hip */
+constexpr uint32_t WALK_CHUNK = 256;         /* segments per queue grab */
+constexpr uint32_t WALK_WGS_PER_XCD = 128;    /* one or two contexts */
+constexpr uint32_t WALK_WGS_CROWD = 32;       /* three or more contexts alive, with claims of 4 x WALK_CHUNK: see bz2_device.hip */
 constexpr uint32_t WALK_QUEUES = 8;
 constexpr uint32_t STASH_BYTES = 128;        /* bytes of a segment the first walk keeps (two 64-B lines per segment: 1 % of the
                                                 bytes lie beyond, 10 % with one line).  Round 3 measured a quarter of the
@@ -250,15 +250,12 @@ k_link2( BlockMeta*                   meta,
 }
 
 /* The walk of the segments.  A lane follows ONE segment at a time, sixteen steps (one 16-byte piece of the segment's stash)
- * per round, and takes its next segment at the start of the round after the one in which it finished one.  Segments are
- * handed out per WAVE: a wave holds a reserve of `chunk` consecutive segments of its XCD's queue (one atomic on the queue's
- * counter when the reserve is empty) and deals them to the lanes that ask, in lane order.  No barriers, no workgroup state:
- * a wave never waits for another one.  What is in flight in an XCD is a window of (lanes + reserves) consecutive segments
- * of the queue, i.e. one or two blocks' tables -- the window is what the XCD's L2 has to hold.
- * (Up to round 2 the lanes of a wave took their next segments together, when the longest of them was through: segment
- * lengths are geometric -- mean 27, the longest of 64 about 128 --, so 22 % of the lanes of a gather instruction were alive,
- * PMC: 10.6 G lane slots for 2.3 G steps.  Round 3 first: claims per workgroup, refill per round inside the claim, a barrier
- * per claim and per block inside it.) */
+ * per round, and takes its next segment at the end of the round in which it finished one.  (Up to round 2 the lanes of a
+ * wave took their next segments together, when the longest of them was through: segment lengths are geometric -- mean 27,
+ * the longest of 64 about 128 --, so 22 % of the lanes of a gather instruction were alive, PMC: 10.6 G lane slots for 2.3 G
+ * steps; the walk is bound by the latency of its dependent gathers, i.e. by how many of them are in flight.)  Within a claim
+ * of `chunk` segments the runs that belong to one block are handled one after the other, so that everything a lane needs to
+ * start a segment is uniform: its number, the stride, and one table look-up. */
 __global__ __launch_bounds__( WALK_THREADS ) void
 k_walk( const BlockMeta* __restrict__ meta,
          const uint32_t* __restrict__  tab_buf,
@@ -267,11 +264,13 @@ k_walk( const BlockMeta* __restrict__ meta,
          const uint32_t* __restrict__  pre,
          uint32_t*                     seg_len,
          uint32_t*                     seg_succ,
-         uint32_t                      chunk,      /* segments per grab of a wave */
+         uint32_t                      chunk,
          uint32_t*                     stash,      /* [block][SEG_STRIDE * STASH_BYTES / 4]: STASH_BYTES bytes per segment */
          uint32_t*                     seg_cont )  /* table index of byte STASH_BYTES of a longer segment */
 {
-    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ uint32_t sBase, sNext, sK0;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
     uint32_t xcc;
     asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"( xcc ) );
     xcc &= WALK_QUEUES - 1;
@@ -281,86 +280,103 @@ k_walk( const BlockMeta* __restrict__ meta,
         const uint32_t qb = plan->q_begin[q], qe = plan->q_begin[q + 1];
         const uint32_t total = plan->q_total[q];
         if ( total == 0 ) continue;
-
-        uint32_t resNext = 0, resEnd = 0;      /* the wave's reserve [resNext, resEnd) of the queue's segments (uniform) */
-        bool drained = false;                  /* the queue has nothing more for this wave (uniform) */
-        uint32_t k = qb;                       /* entry of the queue that holds the lane's segment (only ever grows) */
-        bool idle = true;                      /* no segment under way */
-        uint32_t N = 0, stride = 1, origPtr = 0, k0 = 0, j = 0, p = 0, e = 0, len = 0, piece = 0;
-        const uint32_t* tab = tab_buf;
-        size_t segBase = 0;
         for ( ;; ) {
-            const uint64_t asking = __ballot( idle );
-            if ( asking != 0 && !drained ) {
-                if ( resNext == resEnd ) {
-                    uint32_t base = 0;
-                    if ( lane == 0 ) base = atomicAdd( &plan->ctr[q], chunk );
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane( (int)base );
-                    resNext = base < total ? base : total;
-                    resEnd = total - resNext < chunk ? total : resNext + chunk;
-                    drained = resNext == resEnd;     /* (the counter only grows) */
+            __syncthreads();   /* everyone is done with sBase / sK0 of the previous claim */
+            if ( tid == 0 ) {
+                const uint32_t base = atomicAdd( &plan->ctr[q], chunk );
+                sBase = base;
+                /* last entry k in [qb, qe) with pre[k] <= base */
+                uint32_t lo = qb, hi = qe;
+                while ( hi - lo > 1 ) {
+                    const uint32_t mid = ( lo + hi ) >> 1;
+                    if ( pre[mid] <= base ) lo = mid; else hi = mid;
                 }
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( asking >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)asking, 0 ) );
-                if ( idle && resNext + rank < resEnd ) {
-                    const uint32_t flat = resNext + rank;
-                    while ( k + 1 < qe && flat >= pre[k + 1] ) ++k;      /* (blocks without segments are skipped) */
-                    const uint32_t b = blk[k];
-                    j = flat - pre[k];
-                    N = meta[b].n;
-                    stride = meta[b].seg_stride;
-                    origPtr = meta[b].orig_ptr;
-                    k0 = ( N + stride - 1 ) / stride;
-                    tab = tab_buf + (size_t)b * TAB_STRIDE;
-                    segBase = (size_t)b * SEG_STRIDE;
-                    p = j < k0 ? j * stride : origPtr;
-                    e = tab[p];
-                    len = 0;
-                    piece = 0;
-                    idle = false;
-                }
-                const uint32_t asked = (uint32_t)__popcll( asking );
-                resNext = resEnd - resNext < asked ? resEnd : resNext + asked;
+                sK0 = lo;
             }
-            if ( __ballot( !idle ) == 0 ) {
-                if ( drained ) break;      /* every lane is through and the queue is empty */
-                continue;                  /* (the reserve ran out exactly: grab again) */
-            }
-            if ( !idle ) {
-                uint32_t w[4] = { 0, 0, 0, 0 };
-                bool done = false;
-                if ( piece == STASH_BYTES / 16 ) __builtin_nontemporal_store( p, seg_cont + segBase + j );   /* table index of byte STASH_BYTES */
-                /* four steps per look at `done`: a lane whose segment ends inside the four goes on in place (it re-reads
-                 * its last entry, adds nothing) instead of costing every step a change of the execution mask */
+            __syncthreads();
+            uint32_t base = sBase;
+            if ( base >= total ) break;   /* queue exhausted (the counter only grows) */
+            const uint32_t claimEnd = total - base < chunk ? total : base + chunk;
+            uint32_t k = sK0;
+            /* the runs of the claim that belong to one block each */
+            while ( base < claimEnd ) {
+                while ( k + 1 < qe && base >= pre[k + 1] ) ++k;      /* (blocks without segments are skipped) */
+                const uint32_t runEnd = ( k + 1 < qe && pre[k + 1] < claimEnd ) ? pre[k + 1] : claimEnd;
+                const uint32_t cnt = runEnd - base;
+                const uint32_t b = blk[k];
+                const uint32_t j0 = base - pre[k];
+                const uint32_t N = meta[b].n, stride = meta[b].seg_stride, origPtr = meta[b].orig_ptr;
+                const uint32_t k0 = ( N + stride - 1 ) / stride;
+                const uint32_t* const tab = tab_buf + (size_t)b * TAB_STRIDE;
+                const size_t segBase = (size_t)b * SEG_STRIDE;
+                uint32_t* const stashOfBlock = stash + segBase * ( STASH_BYTES / 4 );
+                __syncthreads();           /* the previous run's sNext has been read by everybody */
+                if ( tid == 0 ) sNext = WALK_THREADS;
+                __syncthreads();
+
+                uint32_t my = tid;         /* segment of the run this lane works on / asks for */
+                bool idle = true;          /* no segment under way */
+                uint32_t j = 0, p = 0, e = 0, len = 0, piece = 0;
+                for ( ;; ) {
+                    if ( idle && my < cnt ) {
+                        j = j0 + my;
+                        p = j < k0 ? j * stride : origPtr;
+                        e = tab[p];
+                        len = 0;
+                        piece = 0;
+                        idle = false;
+                    }
+                    if ( __ballot( !idle ) == 0 ) break;     /* this wave's lanes have found no more segments */
+                    if ( !idle ) {
+                        uint32_t w[4] = { 0, 0, 0, 0 };
+                        bool done = false;
+                        if ( piece == STASH_BYTES / 16 ) __builtin_nontemporal_store( p, seg_cont + segBase + j );   /* table index of byte STASH_BYTES */
+                        /* four steps per look at `done`: a lane whose segment ends inside the four goes on in place (it
+                         * re-reads its last entry, adds nothing) instead of costing every step a change of the execution mask */
 #pragma unroll
-                for ( uint32_t i = 0; i < 16; i += 4 ) {
-                    if ( !done ) {
+                        for ( uint32_t i = 0; i < 16; i += 4 ) {
+                            if ( !done ) {
 #pragma unroll
-                        for ( uint32_t s4 = i; s4 < i + 4; ++s4 ) {
-                            const uint32_t live = done ? 0u : 1u;
-                            w[s4 >> 2] |= done ? 0u : ( e & 0xFFu ) << ( 8 * ( s4 & 3u ) );
-                            len += live;
-                            p = done ? p : ( e >> 8 ) & LF_MASK;
-                            e = tab[p];
-                            done = ( e & MARK ) || len >= N;
+                                for ( uint32_t s4 = i; s4 < i + 4; ++s4 ) {
+                                    const uint32_t live = done ? 0u : 1u;
+                                    w[s4 >> 2] |= done ? 0u : ( e & 0xFFu ) << ( 8 * ( s4 & 3u ) );
+                                    len += live;
+                                    p = done ? p : ( e >> 8 ) & LF_MASK;
+                                    e = tab[p];
+                                    done = ( e & MARK ) || len >= N;
+                                }
+                            }
+                        }
+                        if ( piece < STASH_BYTES / 16 ) {
+                            /* the segment's first STASH_BYTES bytes, walk order, 16 bytes per store: k_emit then needs no second
+                             * gather pass for them.  Written once, read much later: kept out of the way of the table lines */
+                            uint32_t* const out = stashOfBlock + (size_t)j * ( STASH_BYTES / 4 ) + 4 * piece;
+                            __builtin_nontemporal_store( w[0], out );
+                            __builtin_nontemporal_store( w[1], out + 1 );
+                            __builtin_nontemporal_store( w[2], out + 2 );
+                            __builtin_nontemporal_store( w[3], out + 3 );
+                        }
+                        ++piece;
+                        if ( done ) {
+                            __builtin_nontemporal_store( len, seg_len + segBase + j );
+                            const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
+                            __builtin_nontemporal_store( ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu, seg_succ + segBase + j );
+                            idle = true;
+                        }
+                    }
+                    /* the lanes that are through take the next segments of the run: one LDS atomic per wave */
+                    {
+                        const uint64_t asking = __ballot( idle );
+                        if ( asking != 0 ) {
+                            uint32_t first = 0;
+                            if ( lane == (uint32_t)__builtin_ctzll( asking ) ) first = atomicAdd( &sNext, (uint32_t)__popcll( asking ) );
+                            first = (uint32_t)__builtin_amdgcn_readlane( (int)first, __builtin_ctzll( asking ) );
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( asking >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)asking, 0 ) );
+                            if ( idle ) my = first < cnt ? first + rank : cnt;     /* (the counter is left alone once it has passed the end) */
                         }
                     }
                 }
-                if ( piece < STASH_BYTES / 16 ) {
-                    /* the segment's first STASH_BYTES bytes, walk order, 16 bytes per store: k_emit then needs no second
-                     * gather pass for them.  Written once, read much later: kept out of the way of the table lines */
-                    uint32_t* const out = stash + ( segBase + j ) * ( STASH_BYTES / 4 ) + 4 * piece;
-                    __builtin_nontemporal_store( w[0], out );
-                    __builtin_nontemporal_store( w[1], out + 1 );
-                    __builtin_nontemporal_store( w[2], out + 2 );
-                    __builtin_nontemporal_store( w[3], out + 3 );
-                }
-                ++piece;
-                if ( done ) {
-                    __builtin_nontemporal_store( len, seg_len + segBase + j );
-                    const bool isOrig = ( p == origPtr ) && ( origPtr % stride != 0 );
-                    __builtin_nontemporal_store( ( e & MARK ) ? ( isOrig ? k0 : p / stride ) : 0xFFFFFFFFu, seg_succ + segBase + j );
-                    idle = true;
-                }
+                base = runEnd;
             }
         }
     }
