@@ -1,5 +1,6 @@
-"""Developer probe: stage-1 variants side by side -- single blocks, a 320-block batch, the whole 2 560-block batch.
-Prints wall time per batch and the per-kernel event durations (k_hscan / k_hsym / k_mtf)."""
+"""Developer probe: latency of small batches -- single blocks, eight, a 320-block batch, the whole 2 560-block batch -- on one
+context.  Prints the best wall time of four per batch and the per-kernel event durations.  Arguments: labels, one line each
+(set the MI355X_BZ2_* knobs of INTEGRATION.md in the environment to compare forms)."""
 import os
 import sys
 import time
@@ -27,7 +28,6 @@ def main():
         offs = [offsets[i] for i in idx]
         a, r = dec.make_arrays(offs)
         for mode in modes:
-            os.environ["MI355X_BZ2_HUFF"] = mode
             dec.decode_batch_into(a, len(offs), r)
             best = 1e9
             for rep in range(4):
