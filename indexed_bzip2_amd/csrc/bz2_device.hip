@@ -1246,7 +1246,9 @@ mi355x_bz2_decode_batch_begin( mi355x_bz2_ctx* c, const uint64_t* offsets, uint3
         TIMED_LAUNCH( c, g, q, 4, k_link2, dim3( m ), dim3( LINK_THREADS ), sizeof( LinkShared ), q, meta, segLen, segSucc, chain );
         TIMED_LAUNCH( c, g, q, 5, k_emit, dim3( ( SEG_STRIDE + EMIT_THREADS * EMIT_TILES - 1 ) / ( EMIT_THREADS * EMIT_TILES ), m ), dim3( EMIT_THREADS ), 0, q,
                       meta, tab, chain, stash, segCont, rbuf );
-        TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, lcol );
+        static_assert( (size_t)SEG_STRIDE * STASH_BYTES >= L_STRIDE );
+        TIMED_LAUNCH( c, g, q, 6, k_replicate, dim3( m ), dim3( 256 ), 0, q, meta, rbuf, reinterpret_cast<uint8_t*>( stash ),
+                      (size_t)SEG_STRIDE * STASH_BYTES );
         TIMED_LAUNCH( c, g, q, 7, k_rle<false>, dim3( m ), dim3( RLE_THREADS ), 0, q, meta, rbuf, (uint8_t*)nullptr );
         if ( g >= 1 ) {
             HIP_TRY( c, hipEventRecord( c->evGroupDone[g], q ) );

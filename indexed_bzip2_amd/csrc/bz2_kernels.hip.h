@@ -480,12 +480,13 @@ k_bwt_rank( const BlockMeta* __restrict__ meta,
  * walk here produced Y[k] = X[c-1-k] at R[N-1-k], k < c.  In terms of k that is R[N-1-k] = Y[(k - r) mod c] with
  * r = N mod c.  Periodic data (valid streams) always has c | N: r = 0 and the first period is simply repeated.  r != 0
  * only happens for damaged blocks (whose CRC then fails in the reference, too), but the bytes and therefore the
- * calculated CRC still have to be the reference's: the period is parked in `tmp_buf` (the block's L column, no longer
- * needed) and laid out again with the shift. */
+ * calculated CRC still have to be the reference's: the period is parked in `tmp_buf` (the block's stash, which k_emit has
+ * read by now; not the L column: R lies in its memory) and laid out again with the shift. */
 __global__ __launch_bounds__( 256 ) void
 k_replicate( const BlockMeta* __restrict__ meta,
              uint8_t*                      r_buf,
-             uint8_t*                      tmp_buf )
+             uint8_t*                      tmp_buf,
+             size_t                        tmp_stride )    /* bytes per block in tmp_buf, at least L_STRIDE */
 {
     const uint32_t b = blockIdx.x;
     const BlockMeta mt = meta[b];
@@ -499,7 +500,7 @@ k_replicate( const BlockMeta* __restrict__ meta,
         }
         return;
     }
-    uint8_t* const Y = tmp_buf + (size_t)b * L_STRIDE;
+    uint8_t* const Y = tmp_buf + (size_t)b * tmp_stride;
     for ( uint32_t k = threadIdx.x; k < c; k += 256 ) Y[k] = R[N - 1 - k];
     __syncthreads();
     for ( uint32_t k = threadIdx.x; k < N; k += 256 ) {

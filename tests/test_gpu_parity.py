@@ -193,6 +193,18 @@ def test_device_memory_and_the_stage_buffers(native, oracle):
             with pytest.raises(native.Bz2Error):
                 plain.debug_stage(0, stage)
         assert len(plain.debug_stage(0, 1)) == 4 * len(lcol)       # the table is its own buffer either way
+        # the same records from both for damaged blocks (a walk that closes early lays its period out again through a
+        # buffer of its own: it must not be one of the two that share their memory)
+        keys = ("encoded_size_bits", "decoded_size", "computed_crc", "bwt_length", "status")
+        for name, (bad, offs_bad) in datagen.damaged_corpus().items():
+            if not offs_bad:
+                continue
+            got = []
+            for d in (plain, keeping):
+                d.set_input(bad)
+                results_bad, total_bad = d.decode_batch(offs_bad)
+                got.append(([{k: r[k] for k in keys} for r in results_bad], d.copy_output(0, total_bad)))
+            assert got[0] == got[1], name
     finally:
         plain.close()
         keeping.close()
