@@ -82,6 +82,43 @@ def test_silesia_style_slice(native, oracle, dec):
     assert oracle.decode_file(enc)[0] == 0
 
 
+@pytest.mark.parametrize("copies", [10, 31])
+def test_batches_beside_other_contexts(native, oracle, copies):
+    """Three or more contexts alive on a device make the launcher choose its kernels for a crowd (workgroups and claims of the
+    walk, waves per block in the scan, lanes per block in k_mtf, slices of the table build -- by batch size): batches of about 280
+    and 870 blocks of the benchmark corpus on a context as shipped, with three others alive beside it.  (bench.py checks
+    every block's CRC in that situation; here the records and the bytes are compared with the oracle's.)"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import silesia_like, bz2build
+    data = silesia_like.generate(24_000_000, threads=8)
+    enc, nb, offs = bz2build.build(data, 1, piece_size=6_000_000, threads=8, find_magic=native.find_magic)
+    blocks = oracle.find_magic(enc)
+    assert len(blocks) >= 24
+    others = [native.Decoder() for _ in range(3)]
+    d = native.Decoder()
+    try:
+        offsets = [o for _ in range(copies) for o in blocks]
+        d.set_input(enc)
+        results, total = d.decode_batch(offsets)
+        out = d.copy_output(0, total)
+        want = {o: oracle.decode_block(enc, o) for o in blocks}
+        pos = 0
+        for o, r in zip(offsets, results):
+            od, payload = want[o]
+            for key in ("encoded_offset_bits", "encoded_size_bits", "decoded_size", "header_crc", "computed_crc",
+                        "bwt_length", "orig_ptr", "n_symbols", "is_eos", "is_eof", "status"):
+                assert r[key] == od[key], (o, key)
+            assert r["status"] == 0 and r["data_offset"] == pos
+            assert out[pos:pos + r["decoded_size"]] == payload, o
+            pos += r["decoded_size"]
+        assert pos == total == copies * len(data)
+    finally:
+        d.close()
+        for other in others:
+            other.close()
+
+
 def test_gpu_magic_scan(native, oracle, dec):
     """k_find_magic against the oracle / the known answers of src/tests/core/testBitStringFinder.cpp:119-146."""
     M = bytes([0x31, 0x41, 0x59, 0x26, 0x53, 0x59])
